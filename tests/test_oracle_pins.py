@@ -1,0 +1,102 @@
+"""Pins the CPU oracle (oracle/oracle.c) against outputs of the UNMODIFIED reference.
+
+The reference cannot be compiled in this image without stand-in headers, so the pins are the
+reference-run outputs the survey stage recorded in BASELINE.md section 2 / SURVEY.md section 6
+(same scenes, same global xorshift32 stream seeded 0x12345678, reference loop myapp.cpp:163-175):
+
+  * first RandomFloat() from seed 0x12345678 = 0.52966851              
+  * smoke scene 64x64 @1spp: mean RGB = (0.340035, 0.360720, 0.248226), 0 outliers, 71 BVH nodes
+  * 69,938-tri heightfield, single DisneyDiffuse lobe, 1280x720 @1spp:
+        107,269 nodes, max depth 20, avg leaf depth 16.1, 2,773,394 rays = 2,168,523 closest + 604,871 any-hit
+  * 260,642-tri heightfield, DisneyMaterial(.5, 0) + NEE/MIS, 960x540 @1spp:
+        393,989 nodes, max depth 23, avg leaf depth 18.0, max 2 prims/leaf, 1,526,580 rays
+
+Exact integer ray counts over ~1.4 M chaotic paths pin traversal, triangle/sphere tests, BSDF sampling,
+light sampling, MIS and the RNG draw order; the 6-digit mean pins the radiance arithmetic.
+"""
+import numpy as np
+import pytest
+
+
+def bvh_stats(nodes):
+    maxd = leaves = sumd = nn = maxleaf = 0
+    stack = [(0, 0)]
+    while stack:
+        i, d = stack.pop()
+        nn += 1
+        n = nodes[i]
+        if n["count"] > 0:
+            leaves += 1
+            sumd += d
+            maxd = max(maxd, d)
+            maxleaf = max(maxleaf, int(n["count"]))
+        else:
+            stack.append((int(n["first"]), d + 1))
+            stack.append((int(n["first"]) + 1, d + 1))
+    return nn, leaves, maxd, sumd / leaves, maxleaf
+
+
+def test_rng_first_floats(oracle):
+    f, u = oracle.rng_floats(0x12345678, 2)
+    assert "%.8f" % f[0] == "0.52966851"
+    # cl/tools.cl:2 WangHash known values (computed by hand from the 5-line definition)
+    s = 17
+    s = ((s ^ 61) ^ (s >> 16)) & 0xFFFFFFFF
+    s = (s * 9) & 0xFFFFFFFF
+    s = s ^ (s >> 4)
+    s = (s * 0x27d4eb2d) & 0xFFFFFFFF
+    s = s ^ (s >> 15)
+    assert oracle.wang_hash(17) == s
+    assert oracle.sample_seed(0, 64 * 64, 0, 0) == s
+
+
+def smoke_scene(ob):
+    s = ob.OracleScene()
+    floor = s.add_material(ob.MAT_DISNEY, ob.hex2lin(0xcbceb1), 1.0, 0.0)
+    gold = s.add_material(ob.MAT_DISNEY, [0.944, 0.776, 0.373], 0.5, 1.0)
+    v, n, t, idx = ob.create_backdrop([0, -1, 20], [40, 20, 40], 7.5, 32)
+    mesh = s.add_mesh(v, n, t, idx, floor, 1)
+    s.add_sphere([0, 0, 0], 1.0, gold)
+    s.add_area_light([0, 25, -20], 1.0, np.float32([1, .941, .914]) * np.float32(200))
+    s.add_uniform_infinite_light([.4, .45, .5])
+    s.set_camera([-1.46, 1.16, -4.64], [0, 0, 0], [0, 1, 0], 1.0, 45.0, 0.0)
+    return s, mesh
+
+
+def test_smoke_scene_mean_rgb(oracle):
+    s, mesh = smoke_scene(oracle)
+    nodes, order = s.bvh(mesh)
+    assert len(nodes) - 1 == 71
+    acc, st = s.render(64, 64, 1, seed_base=0x12345678, rng_mode=oracle.RNG_GLOBAL)
+    mean = acc[..., :3].astype(np.float64).reshape(-1, 3).mean(0)
+    assert ["%.6f" % m for m in mean] == ["0.340035", "0.360720", "0.248226"]
+    assert st.outliers == 0 and st.samples == 64 * 64
+
+
+def heightfield_run(ob, quads, W, H, disney):
+    s = ob.OracleScene()
+    if disney:
+        mat = s.add_material(ob.MAT_DISNEY, ob.hex2lin(0xc5b5d2), .5, 0.)
+    else:
+        mat = s.add_material(ob.MAT_DIFFUSE_ONLY, [.7, .7, .7])
+    v, n, t, idx = ob.pin_heightfield(quads, 2.0)
+    m = s.add_mesh(v, n, t, idx, mat, 1)
+    nodes, _ = s.bvh(m)
+    s.add_area_light([0, 6, -3], 1.0, np.float32([1, .941, .914]) * np.float32(60))
+    s.add_uniform_infinite_light([.4, .45, .5])
+    s.set_camera([0, 2.2, -4.2], [0, 0, 0], [0, 1, 0], np.float32(W) / np.float32(H), 40.0, 0.0)
+    acc, st = s.render(W, H, 1, seed_base=0x12345678, rng_mode=ob.RNG_GLOBAL)
+    return bvh_stats(nodes), st
+
+
+def test_heightfield_70k_diffuse_ray_counts(oracle):
+    (nn, leaves, maxd, avgd, maxleaf), st = heightfield_run(oracle, 187, 1280, 720, False)
+    assert (nn, maxd, "%.1f" % avgd) == (107269, 20, "16.1")
+    assert (st.closest_rays, st.anyhit_rays) == (2168523, 604871)
+    assert st.rays == 2773394 and st.outliers == 0
+
+
+def test_heightfield_260k_disney_ray_counts(oracle):
+    (nn, leaves, maxd, avgd, maxleaf), st = heightfield_run(oracle, 361, 960, 540, True)
+    assert (nn, maxd, "%.1f" % avgd, maxleaf) == (393989, 23, "18.0", 2)
+    assert st.rays == 1526580 and st.outliers == 0
