@@ -1,0 +1,651 @@
+// agpt_api.hip -- the C ABI of include/agpt.h on top of the kernels in agpt_kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/agpt.h"
+#include "agpt_host_scene.hpp"
+#include "agpt_kernels.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(AGPT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return AGPT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) return fail(AGPT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        n = count;
+        return AGPT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct agpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // path-state pool (sized for the largest batch seen)
+    size_t pool_paths = 0;
+    DevBuf<float4> ext_o, ext_d, sh_o, sh_d, mis_o, mis_d, beta4, L4, fac4, c1, c2;
+    DevBuf<DevHit> hit, mis_hit;
+    DevBuf<uint32_t> occluded;
+    DevBuf<uint32_t> q[2][4];
+    DevBuf<uint32_t> qcounts;   // 2 x 4 queue lengths
+    DevBuf<uint32_t> work;      // work-queue heads of the persistent trace launches
+    DevBuf<DevCounters> counters;
+    uint32_t* host_pinned = nullptr;
+};
+
+struct agpt_scene {
+    agpt_ctx* ctx = nullptr;
+    std::vector<agpt::HostMesh> meshes;
+    std::vector<agpt::HostSphere> spheres;
+    std::vector<agpt::HostPrim> prims;
+    std::vector<agpt::HostLight> lights;
+    std::vector<DevMaterial> materials;
+    DevCamera cam{};
+    bool has_camera = false;
+    bool committed = false;
+    int max_depth = 0;
+    DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade;
+    DevBuf<DevPrim> d_prims;
+    DevBuf<DevMaterial> d_materials;
+    DevBuf<DevLight> d_lights;
+    DevScene dev{};
+};
+
+template <class T>
+static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
+    int rc = buf.ensure(host.empty() ? 1 : host.size());
+    if (rc) return rc;
+    if (!host.empty()) HIP_TRY(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return AGPT_OK;
+}
+
+static int trace_grid(const agpt_ctx* c) { return c->num_cus * 4; }
+
+template <bool ANY>
+static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
+                         uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, bool count) {
+    dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
+    if (count)
+        hipLaunchKernelGGL((k_trace<ANY, true>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
+                           hits, occ, c->counters.p);
+    else
+        hipLaunchKernelGGL((k_trace<ANY, false>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
+                           hits, occ, c->counters.p);
+}
+
+extern "C" {
+
+const char* agpt_last_error(void) { return g_error.c_str(); }
+int agpt_version(void) { return 1; }
+
+int agpt_init(int device, agpt_ctx** out) {
+    if (!out) return fail(AGPT_ERR_INVALID, "agpt_init: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(AGPT_ERR_DEVICE, "agpt_init: no HIP device (the MI355X path has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(AGPT_ERR_INVALID, "agpt_init: bad device index");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<agpt_ctx> c(new agpt_ctx());
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(uint32_t)));
+    *out = c.release();
+    return AGPT_OK;
+}
+
+int agpt_set_stream(agpt_ctx* c, void* s) {
+    if (!c) return fail(AGPT_ERR_INVALID, "agpt_set_stream: ctx is NULL");
+    c->stream = (hipStream_t)s;
+    return AGPT_OK;
+}
+
+void agpt_destroy(agpt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4,
+                              &c->c1, &c->c2})
+        b->release();
+    c->hit.release();
+    c->mis_hit.release();
+    c->occluded.release();
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 4; j++) c->q[i][j].release();
+    c->qcounts.release();
+    c->work.release();
+    c->counters.release();
+    if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete c;
+}
+
+// ---- scene building -----------------------------------------------------------------------------------------
+int agpt_scene_create(agpt_ctx* c, agpt_scene** out) {
+    if (!c || !out) return fail(AGPT_ERR_INVALID, "agpt_scene_create: NULL argument");
+    agpt_scene* s = new agpt_scene();
+    s->ctx = c;
+    *out = s;
+    return AGPT_OK;
+}
+
+void agpt_scene_destroy(agpt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipDeviceSynchronize();
+    s->d_nodes.release();
+    s->d_tri_verts.release();
+    s->d_tri_shade.release();
+    s->d_prims.release();
+    s->d_materials.release();
+    s->d_lights.release();
+    delete s;
+}
+
+int agpt_scene_add_material(agpt_scene* s, int type, const float color[3], float roughness, float metallic) {
+    if (!s || !color) return fail(AGPT_ERR_INVALID, "agpt_scene_add_material: NULL argument");
+    if (type < AGPT_MAT_DISNEY || type > AGPT_MAT_DIFFUSE_ONLY) return fail(AGPT_ERR_INVALID, "unknown material type");
+    s->materials.push_back(agpt::make_material(type, color, roughness, metallic));
+    s->committed = false;
+    return (int)s->materials.size() - 1;
+}
+
+int agpt_scene_add_mesh(agpt_scene* s, const float* vertices, int n_vertices, const float* normals, int n_normals,
+                        const float* texcoords, int n_texcoords, const int32_t* indices, int n_indices, int material,
+                        int max_prims_in_node) {
+    if (!s || !vertices || !indices) return fail(AGPT_ERR_INVALID, "agpt_scene_add_mesh: NULL argument");
+    if (n_indices < 3 || n_indices % 3 != 0 || n_vertices <= 0)
+        return fail(AGPT_ERR_INVALID, "agpt_scene_add_mesh: need at least one triangle (the reference's BVH build does not terminate on an empty mesh)");
+    if (material < -1 || material >= (int)s->materials.size()) return fail(AGPT_ERR_INVALID, "agpt_scene_add_mesh: bad material id");
+    for (int i = 0; i < n_indices; i++) {
+        const int32_t* ix = indices + 3 * i;
+        if (ix[0] < 0 || ix[0] >= n_vertices) return fail(AGPT_ERR_INVALID, "agpt_scene_add_mesh: vertex index out of range");
+        if (n_normals > 0 && (ix[1] < 0 || ix[1] >= n_normals)) return fail(AGPT_ERR_INVALID, "agpt_scene_add_mesh: normal index out of range");
+        if (n_texcoords > 0 && (ix[2] < 0 || ix[2] >= n_texcoords)) return fail(AGPT_ERR_INVALID, "agpt_scene_add_mesh: texcoord index out of range");
+    }
+    agpt::HostMesh m;
+    m.vertices.resize(n_vertices);
+    for (int i = 0; i < n_vertices; i++) m.vertices[i] = V3(vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]);
+    if (normals && n_normals > 0) {
+        m.normals.resize(n_normals);
+        for (int i = 0; i < n_normals; i++) m.normals[i] = V3(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+    }
+    if (texcoords && n_texcoords > 0) {
+        m.texcoords.resize(n_texcoords);
+        for (int i = 0; i < n_texcoords; i++) {
+            m.texcoords[i].x = texcoords[2 * i];
+            m.texcoords[i].y = texcoords[2 * i + 1];
+        }
+    }
+    m.indices.assign(indices, indices + (size_t)3 * n_indices);
+    m.material = material;
+    agpt::build_bvh(m, max_prims_in_node);
+    s->meshes.push_back(std::move(m));
+    agpt::HostPrim p;
+    p.type = AGPT_PRIM_MESH;
+    p.index = (int)s->meshes.size() - 1;
+    p.material = material;
+    p.arealight = -1;
+    s->prims.push_back(p);
+    s->committed = false;
+    return (int)s->prims.size() - 1;
+}
+
+int agpt_scene_add_sphere(agpt_scene* s, const float center[3], float radius, int material) {
+    if (!s || !center) return fail(AGPT_ERR_INVALID, "agpt_scene_add_sphere: NULL argument");
+    if (material < -1 || material >= (int)s->materials.size()) return fail(AGPT_ERR_INVALID, "agpt_scene_add_sphere: bad material id");
+    agpt::HostSphere sp;
+    sp.center = V3(center[0], center[1], center[2]);
+    sp.r = radius;
+    sp.r2 = radius * radius;
+    s->spheres.push_back(sp);
+    agpt::HostPrim p;
+    p.type = AGPT_PRIM_SPHERE;
+    p.index = (int)s->spheres.size() - 1;
+    p.material = material;
+    p.arealight = -1;
+    s->prims.push_back(p);
+    s->committed = false;
+    return (int)s->prims.size() - 1;
+}
+
+int agpt_scene_add_area_light(agpt_scene* s, const float center[3], float radius, const float L[3]) {
+    if (!s || !center || !L) return fail(AGPT_ERR_INVALID, "agpt_scene_add_area_light: NULL argument");
+    int prim = agpt_scene_add_sphere(s, center, radius, -1);
+    if (prim < 0) return prim;
+    agpt::HostLight l;
+    l.type = AGPT_LIGHT_AREA;
+    l.shape = prim;
+    l.L = V3(L[0], L[1], L[2]);
+    s->lights.push_back(l);
+    s->prims[prim].arealight = (int)s->lights.size() - 1;
+    return prim;
+}
+
+int agpt_scene_add_uniform_infinite_light(agpt_scene* s, const float L[3]) {
+    if (!s || !L) return fail(AGPT_ERR_INVALID, "agpt_scene_add_uniform_infinite_light: NULL argument");
+    agpt::HostLight l;
+    l.type = AGPT_LIGHT_UNIFORM_INFINITE;
+    l.shape = -1;
+    l.L = V3(L[0], L[1], L[2]);
+    s->lights.push_back(l);
+    s->committed = false;
+    return (int)s->lights.size() - 1;
+}
+
+int agpt_scene_set_camera(agpt_scene* s, const agpt_camera_desc* d) {
+    if (!s || !d) return fail(AGPT_ERR_INVALID, "agpt_scene_set_camera: NULL argument");
+    s->cam = agpt::make_camera(*d);
+    s->has_camera = true;
+    s->dev.cam = s->cam;
+    return AGPT_OK;
+}
+
+int agpt_scene_commit(agpt_scene* s) {
+    if (!s) return fail(AGPT_ERR_INVALID, "agpt_scene_commit: scene is NULL");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    agpt::FlatScene flat;
+    agpt::flatten_scene(s->meshes, s->spheres, s->prims, flat);
+    s->max_depth = flat.max_depth;
+    if (flat.max_depth > AGPT_STACK_DEPTH)
+        return fail(AGPT_ERR_LIMIT, "agpt_scene_commit: BVH depth " + std::to_string(flat.max_depth) +
+                                        " exceeds the traversal stack (" + std::to_string(AGPT_STACK_DEPTH) + ")");
+    std::vector<DevLight> lights(s->lights.size());
+    int n_inf = 0;
+    for (size_t i = 0; i < lights.size(); i++) {
+        lights[i].type = s->lights[i].type;
+        lights[i].shape = s->lights[i].shape;
+        lights[i].L[0] = s->lights[i].L.x;
+        lights[i].L[1] = s->lights[i].L.y;
+        lights[i].L[2] = s->lights[i].L.z;
+        if (lights[i].type == AGPT_LIGHT_UNIFORM_INFINITE) n_inf++;
+    }
+    hipStream_t st = s->ctx->stream;
+    int rc;
+    if ((rc = upload(s->d_nodes, flat.nodes, st))) return rc;
+    if ((rc = upload(s->d_tri_verts, flat.tri_verts, st))) return rc;
+    if ((rc = upload(s->d_tri_shade, flat.tri_shade, st))) return rc;
+    if ((rc = upload(s->d_prims, flat.prims, st))) return rc;
+    if ((rc = upload(s->d_materials, s->materials, st))) return rc;
+    if ((rc = upload(s->d_lights, lights, st))) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    s->dev.nodes = s->d_nodes.p;
+    s->dev.tri_verts = s->d_tri_verts.p;
+    s->dev.tri_shade = s->d_tri_shade.p;
+    s->dev.prims = s->d_prims.p;
+    s->dev.materials = s->d_materials.p;
+    s->dev.lights = s->d_lights.p;
+    s->dev.n_prims = (int)flat.prims.size();
+    s->dev.n_lights = (int)lights.size();
+    s->dev.n_materials = (int)s->materials.size();
+    s->dev.n_infinite = n_inf;
+    s->dev.cam = s->cam;
+    s->committed = true;
+    return AGPT_OK;
+}
+
+static const agpt::HostMesh* mesh_of(const agpt_scene* s, int prim) {
+    if (!s || prim < 0 || prim >= (int)s->prims.size() || s->prims[prim].type != AGPT_PRIM_MESH) return nullptr;
+    return &s->meshes[s->prims[prim].index];
+}
+int agpt_mesh_num_nodes(const agpt_scene* s, int prim) {
+    const agpt::HostMesh* m = mesh_of(s, prim);
+    return m ? m->total_nodes : fail(AGPT_ERR_INVALID, "agpt_mesh_num_nodes: not a mesh primitive");
+}
+int agpt_mesh_num_prims(const agpt_scene* s, int prim) {
+    const agpt::HostMesh* m = mesh_of(s, prim);
+    return m ? (int)m->prim_index.size() : fail(AGPT_ERR_INVALID, "agpt_mesh_num_prims: not a mesh primitive");
+}
+int agpt_mesh_get_bvh(const agpt_scene* s, int prim, agpt_bvh_node* nodes_out, int32_t* prim_index_out) {
+    const agpt::HostMesh* m = mesh_of(s, prim);
+    if (!m) return fail(AGPT_ERR_INVALID, "agpt_mesh_get_bvh: not a mesh primitive");
+    if (nodes_out) std::memcpy(nodes_out, m->nodes.data(), m->nodes.size() * sizeof(agpt_bvh_node));
+    if (prim_index_out) std::memcpy(prim_index_out, m->prim_index.data(), m->prim_index.size() * sizeof(int32_t));
+    return AGPT_OK;
+}
+
+int agpt_bvh_build(const float* vertices, int n_vertices, const int32_t* indices, int n_indices, int max_prims_in_node,
+                   agpt_bvh_node* nodes_out, int32_t* prim_index_out, int* total_nodes_out, int* max_depth_out) {
+    if (!vertices || !indices || n_vertices <= 0 || n_indices < 3 || n_indices % 3 != 0)
+        return fail(AGPT_ERR_INVALID, "agpt_bvh_build: need at least one triangle");
+    for (int i = 0; i < n_indices; i++)
+        if (indices[3 * i] < 0 || indices[3 * i] >= n_vertices) return fail(AGPT_ERR_INVALID, "agpt_bvh_build: vertex index out of range");
+    agpt::HostMesh m;
+    m.vertices.resize(n_vertices);
+    for (int i = 0; i < n_vertices; i++) m.vertices[i] = V3(vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]);
+    m.indices.assign(indices, indices + (size_t)3 * n_indices);
+    agpt::build_bvh(m, max_prims_in_node);
+    if (nodes_out) std::memcpy(nodes_out, m.nodes.data(), m.nodes.size() * sizeof(agpt_bvh_node));
+    if (prim_index_out) std::memcpy(prim_index_out, m.prim_index.data(), m.prim_index.size() * sizeof(int32_t));
+    if (total_nodes_out) *total_nodes_out = m.total_nodes;
+    if (max_depth_out) *max_depth_out = m.max_depth;
+    return AGPT_OK;
+}
+
+int agpt_create_backdrop(const float origin[3], const float size[3], float radius, int steps, float* vertices, float* normals,
+                         float* texcoords, int32_t* indices, int* n_vertices, int* n_indices) {
+    if (!origin || !size || !vertices || !normals || !texcoords || !indices || steps < 1)
+        return fail(AGPT_ERR_INVALID, "agpt_create_backdrop: bad argument");
+    std::vector<v3> v, n;
+    std::vector<v2> t;
+    std::vector<int32_t> ix;
+    agpt::create_backdrop(V3(origin[0], origin[1], origin[2]), V3(size[0], size[1], size[2]), radius, steps, v, n, t, ix);
+    for (size_t i = 0; i < v.size(); i++) {
+        vertices[3 * i] = v[i].x; vertices[3 * i + 1] = v[i].y; vertices[3 * i + 2] = v[i].z;
+        normals[3 * i] = n[i].x; normals[3 * i + 1] = n[i].y; normals[3 * i + 2] = n[i].z;
+        texcoords[2 * i] = t[i].x; texcoords[2 * i + 1] = t[i].y;
+    }
+    std::memcpy(indices, ix.data(), ix.size() * sizeof(int32_t));
+    if (n_vertices) *n_vertices = (int)v.size();
+    if (n_indices) *n_indices = (int)ix.size() / 3;
+    return AGPT_OK;
+}
+
+// ---- device helpers -----------------------------------------------------------------------------------------
+int agpt_device_alloc(agpt_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return fail(AGPT_ERR_INVALID, "agpt_device_alloc: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(AGPT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return AGPT_OK;
+}
+int agpt_device_free(agpt_ctx* c, void* p) {
+    if (!c) return fail(AGPT_ERR_INVALID, "agpt_device_free: ctx is NULL");
+    if (p) HIP_TRY(hipFree(p));
+    return AGPT_OK;
+}
+int agpt_device_memset(agpt_ctx* c, void* p, int value, size_t bytes) {
+    if (!c || !p) return fail(AGPT_ERR_INVALID, "agpt_device_memset: NULL argument");
+    HIP_TRY(hipMemsetAsync(p, value, bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return AGPT_OK;
+}
+int agpt_device_download(agpt_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return fail(AGPT_ERR_INVALID, "agpt_device_download: NULL argument");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return AGPT_OK;
+}
+int agpt_device_upload(agpt_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return fail(AGPT_ERR_INVALID, "agpt_device_upload: NULL argument");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return AGPT_OK;
+}
+
+// ---- hot path -----------------------------------------------------------------------------------------------
+static int ensure_pool(agpt_ctx* c, size_t paths) {
+    int rc;
+    for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4,
+                              &c->c1, &c->c2})
+        if ((rc = b->ensure(paths))) return rc;
+    if ((rc = c->hit.ensure(paths))) return rc;
+    if ((rc = c->mis_hit.ensure(paths))) return rc;
+    if ((rc = c->occluded.ensure(paths))) return rc;
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 4; j++)
+            if ((rc = c->q[i][j].ensure(paths))) return rc;
+    if ((rc = c->qcounts.ensure(8))) return rc;
+    if ((rc = c->work.ensure(4096))) return rc;
+    if ((rc = c->counters.ensure(1))) return rc;
+    c->pool_paths = paths;
+    return AGPT_OK;
+}
+
+static void read_counters(const DevCounters& d, agpt_stats* st) {
+    st->closest_rays = d.closest_rays;
+    st->anyhit_rays = d.anyhit_rays;
+    st->interior_visits = d.interior;
+    st->tri_tests = d.tris;
+    st->shaded_vertices = d.shaded;
+    st->outliers = d.outliers;
+    st->samples = d.samples;
+}
+
+int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* out, int any_hit, agpt_stats* stats) {
+    if (!s || !rays || !out || n < 0) return fail(AGPT_ERR_INVALID, "agpt_intersect_batch: bad argument");
+    if (!s->committed) return fail(AGPT_ERR_INVALID, "agpt_intersect_batch: scene not committed");
+    if (n == 0) return AGPT_OK;
+    agpt_ctx* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_pool(c, (size_t)n);
+    if (rc) return rc;
+    agpt_ray* d_rays = nullptr;
+    agpt_hit* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * sizeof(agpt_ray)));
+    HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * sizeof(agpt_hit)));
+    HIP_TRY(hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(agpt_ray), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
+    HIP_TRY(hipMemsetAsync(c->work.p, 0, sizeof(uint32_t), c->stream));
+    int blocks = (n + AGPT_BLOCK - 1) / AGPT_BLOCK;
+    hipLaunchKernelGGL(k_prepare_rays, dim3(blocks), dim3(AGPT_BLOCK), 0, c->stream, d_rays, n, c->ext_o.p, c->ext_d.p);
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (any_hit)
+        launch_trace<true>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
+                           stats != nullptr);
+    else
+        launch_trace<false>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
+                            stats != nullptr);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    hipLaunchKernelGGL(k_export_hits, dim3(blocks), dim3(AGPT_BLOCK), 0, c->stream, s->dev, c->hit.p, c->occluded.p, n, any_hit,
+                       d_out);
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(agpt_hit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        DevCounters dc;
+        HIP_TRY(hipMemcpy(&dc, c->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
+        read_counters(dc, stats);
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        stats->trace_ms = ms;
+        stats->total_ms = ms;
+        stats->trace_launches = 1;
+    }
+    HIP_TRY(hipFree(d_rays));
+    HIP_TRY(hipFree(d_out));
+    return AGPT_OK;
+}
+
+int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, agpt_stats* stats) {
+    if (!s || !rp || !accum_dev) return fail(AGPT_ERR_INVALID, "agpt_render: NULL argument");
+    if (!s->committed || !s->has_camera) return fail(AGPT_ERR_INVALID, "agpt_render: scene not committed or camera not set");
+    if (rp->width <= 0 || rp->height <= 0 || rp->w <= 0 || rp->h <= 0 || rp->x0 < 0 || rp->y0 < 0 ||
+        rp->x0 + rp->w > rp->width || rp->y0 + rp->h > rp->height || rp->spp_count < 0 || rp->max_depth < 0 ||
+        rp->max_depth > 200 || rp->accum_pitch < rp->x0 + rp->w)
+        return fail(AGPT_ERR_INVALID, "agpt_render: bad tile / film / sample range");
+    agpt_ctx* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t NP = (uint32_t)rp->w * (uint32_t)rp->h;
+    int S = rp->samples_per_batch > 0 ? rp->samples_per_batch : (int)std::max<uint64_t>(1, (8ull << 20) / NP);
+    S = std::min(S, std::max(1, rp->spp_count));
+    if ((uint64_t)NP * (uint64_t)S > 0x7FFFFFFFull) return fail(AGPT_ERR_LIMIT, "agpt_render: batch too large");
+    int rc = ensure_pool(c, (size_t)NP * S);
+    if (rc) return rc;
+    s->dev.cam = s->cam;
+
+    PathBuffers pb;
+    pb.ext_o = c->ext_o.p; pb.ext_d = c->ext_d.p; pb.sh_o = c->sh_o.p; pb.sh_d = c->sh_d.p;
+    pb.mis_o = c->mis_o.p; pb.mis_d = c->mis_d.p; pb.hit = c->hit.p; pb.mis_hit = c->mis_hit.p;
+    pb.occluded = c->occluded.p; pb.beta4 = c->beta4.p; pb.L4 = c->L4.p; pb.fac4 = c->fac4.p;
+    pb.c1 = c->c1.p; pb.c2 = c->c2.p;
+    Queues q[2];
+    for (int i = 0; i < 2; i++) {
+        q[i].active = c->q[i][0].p; q[i].ext = c->q[i][1].p; q[i].mis = c->q[i][2].p; q[i].shadow = c->q[i][3].p;
+        q[i].counts = c->qcounts.p + 4 * i;
+    }
+    const bool count = rp->enable_counters != 0;
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    uint64_t iterations = 0, launches = 0;
+    const int shade_grid = c->num_cus * 8;
+
+    for (int s0 = rp->spp_begin; s0 < rp->spp_begin + rp->spp_count; s0 += S) {
+        RenderConsts rcn;
+        rcn.W = rp->width; rcn.H = rp->height; rcn.x0 = rp->x0; rcn.y0 = rp->y0; rcn.w = rp->w; rcn.h = rp->h;
+        rcn.s0 = s0; rcn.S = std::min(S, rp->spp_begin + rp->spp_count - s0);
+        rcn.seed_base = rp->seed_base; rcn.max_depth = rp->max_depth;
+        rcn.accum_pitch = rp->accum_pitch; rcn.accum_row0 = rp->accum_row0; rcn.NP = NP;
+        const uint32_t total = NP * (uint32_t)rcn.S;
+        int cur = 0;
+        hipLaunchKernelGGL(k_generate, dim3((total + AGPT_BLOCK - 1) / AGPT_BLOCK), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb,
+                           q[cur]);
+        // a path needs at most max_depth+2 iterations unless it crosses emitter spheres (pass-through re-casts do
+        // not count as bounces); run that many, then keep going while the active queue is non-empty
+        int planned = rp->max_depth + 2;
+        for (int it = 0;; it++) {
+            if (it >= planned) {
+                HIP_TRY(hipMemcpyAsync(c->host_pinned, q[cur].counts, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (c->host_pinned[0] == 0) break;
+                if (it > 4096) return fail(AGPT_ERR_LIMIT, "agpt_render: path did not terminate");
+            }
+            const int nxt = cur ^ 1;
+            HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * sizeof(uint32_t), c->stream));
+            HIP_TRY(hipMemsetAsync(c->work.p, 0, 3 * sizeof(uint32_t), c->stream));
+            launch_trace<false>(c, s->dev, q[cur].ext, &q[cur].counts[1], 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
+            launch_trace<false>(c, s->dev, q[cur].mis, &q[cur].counts[2], 0, c->work.p + 1, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
+            launch_trace<true>(c, s->dev, q[cur].shadow, &q[cur].counts[3], 0, c->work.p + 2, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
+            cur = nxt;
+            iterations++;
+            launches += 3;
+        }
+        hipLaunchKernelGGL(k_accumulate, dim3((NP + AGPT_BLOCK - 1) / AGPT_BLOCK), dim3(AGPT_BLOCK), 0, c->stream, rcn, pb,
+                           (float4*)accum_dev, c->counters.p);
+    }
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::memset(stats, 0, sizeof(*stats));
+        DevCounters dc;
+        HIP_TRY(hipMemcpy(&dc, c->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
+        read_counters(dc, stats);
+        stats->samples = (uint64_t)NP * (uint64_t)rp->spp_count;
+        stats->iterations = iterations;
+        stats->trace_launches = launches;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        stats->total_ms = ms;
+    }
+    return AGPT_OK;
+}
+
+int agpt_resolve(agpt_ctx* c, const float* accum_dev, int n_pixels, int samples, uint32_t* out_rgb) {
+    if (!c || !accum_dev || !out_rgb || n_pixels <= 0 || samples <= 0) return fail(AGPT_ERR_INVALID, "agpt_resolve: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)n_pixels * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, c->stream, (const float4*)accum_dev, n_pixels, samples, d);
+    HIP_TRY(hipMemcpyAsync(out_rgb, d, (size_t)n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d));
+    return AGPT_OK;
+}
+
+// ---- known-answer entry points ------------------------------------------------------------------------------
+int agpt_kat_bsdf_eval(agpt_scene* s, int material, int n, const float* wo3, const float* wi3, float* f3_out, float* pdf_out) {
+    if (!s || !s->committed || material < 0 || material >= (int)s->materials.size() || n <= 0 || !wo3 || !wi3 || !f3_out || !pdf_out)
+        return fail(AGPT_ERR_INVALID, "agpt_kat_bsdf_eval: bad argument");
+    agpt_ctx* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_wo, *d_wi, *d_f, *d_p;
+    HIP_TRY(hipMalloc((void**)&d_wo, 12 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_wi, 12 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_f, 12 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_p, 4 * (size_t)n));
+    HIP_TRY(hipMemcpy(d_wo, wo3, 12 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_wi, wi3, 12 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_bsdf_eval, dim3((n + 63) / 64), dim3(64), 0, c->stream, s->dev, material, n, d_wo, d_wi, d_f, d_p);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(f3_out, d_f, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf_out, d_p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_wo); (void)hipFree(d_wi); (void)hipFree(d_f); (void)hipFree(d_p);
+    return AGPT_OK;
+}
+
+int agpt_kat_bsdf_sample(agpt_scene* s, int material, int n, const float* wo3, const float* u2, float* wi3_out, float* f3_out,
+                         float* pdf_out, int32_t* specular_out) {
+    if (!s || !s->committed || material < 0 || material >= (int)s->materials.size() || n <= 0 || !wo3 || !u2 || !wi3_out ||
+        !f3_out || !pdf_out || !specular_out)
+        return fail(AGPT_ERR_INVALID, "agpt_kat_bsdf_sample: bad argument");
+    agpt_ctx* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_wo, *d_u, *d_wi, *d_f, *d_p;
+    int32_t* d_s;
+    HIP_TRY(hipMalloc((void**)&d_wo, 12 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_u, 8 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_wi, 12 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_f, 12 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_p, 4 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_s, 4 * (size_t)n));
+    HIP_TRY(hipMemcpy(d_wo, wo3, 12 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_u, u2, 8 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_bsdf_sample, dim3((n + 63) / 64), dim3(64), 0, c->stream, s->dev, material, n, d_wo, d_u, d_wi, d_f,
+                       d_p, d_s);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(wi3_out, d_wi, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f3_out, d_f, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf_out, d_p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(specular_out, d_s, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_wo); (void)hipFree(d_u); (void)hipFree(d_wi); (void)hipFree(d_f); (void)hipFree(d_p); (void)hipFree(d_s);
+    return AGPT_OK;
+}
+
+int agpt_kat_rng(agpt_ctx* c, uint32_t pixel, uint32_t wh, uint32_t sample, uint32_t seed_base, int n, float* out,
+                 uint32_t* seed_out) {
+    if (!c || n <= 0 || !out || !seed_out) return fail(AGPT_ERR_INVALID, "agpt_kat_rng: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_o;
+    uint32_t* d_s;
+    HIP_TRY(hipMalloc((void**)&d_o, 4 * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&d_s, 4));
+    hipLaunchKernelGGL(k_kat_rng, dim3(1), dim3(64), 0, c->stream, pixel, wh, sample, seed_base, n, d_o, d_s);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, d_o, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(seed_out, d_s, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_o); (void)hipFree(d_s);
+    return AGPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,448 @@
+// agpt_host_scene.cpp -- host-side scene preparation (runs once per scene; the reference does the same work in
+// BVHTriMesh's constructor, DisneyMaterial's constructor and Camera's constructor).
+#include "agpt_host_scene.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace agpt {
+
+using uv_t = v2;
+
+// ------------------------------------------------------------------------------------------------------------
+// Binned-SAH BVH, built straight into the flattened reference layout.
+//   Primitive            bvhtrimesh.h:132-145   bounds of the 3 vertices, centroid = bounds centre
+//   BuildRecursive       bvhtrimesh.h:213-310   12 buckets along the longest centroid axis, leaf when one prim is
+//                                               left or all centroids coincide on that axis; nth_element for n<=2,
+//                                               std::partition on the winning bucket otherwise
+//   FlattenBVHTree       bvhtrimesh.h:312-330   root at 0, child pairs allocated in pre-order from slot 2
+// std::partition / std::nth_element are the same libstdc++ algorithms the reference calls, so the primitive order
+// inside every subtree -- and with it the traversal order of tied hits -- is reproduced.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    Box() {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = 1e34f;
+            hi[a] = -1e34f;
+        }
+    }
+    void grow(const Box& b) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = tminf(lo[a], b.lo[a]);
+            hi[a] = tmaxf(hi[a], b.hi[a]);
+        }
+    }
+    void grow(v3 p) {
+        lo[0] = tminf(lo[0], p.x);
+        lo[1] = tminf(lo[1], p.y);
+        lo[2] = tminf(lo[2], p.z);
+        hi[0] = tmaxf(hi[0], p.x);
+        hi[1] = tmaxf(hi[1], p.y);
+        hi[2] = tmaxf(hi[2], p.z);
+    }
+    float extent(int a) const { return hi[a] - lo[a]; }
+    int longest_axis() const {
+        int a = 0;
+        if (extent(1) > extent(0)) a = 1;
+        if (extent(2) > extent(a)) a = 2;
+        return a;
+    }
+    float area() const {
+        float dx = extent(0), dy = extent(1), dz = extent(2);
+        return 2 * (dx * dy + dx * dz + dy * dz);
+    }
+    float offset(float p, int a) const {
+        float o = p - lo[a];
+        if (hi[a] > lo[a]) o /= hi[a] - lo[a];
+        return o;
+    }
+};
+
+struct BuildPrim {
+    int32_t index;
+    Box box;
+    float c[3];
+};
+
+constexpr int kBuckets = 12;
+
+struct Builder {
+    std::vector<BuildPrim> prims;
+    std::vector<agpt_bvh_node>& nodes;
+    int max_prims;
+    int next_pair = 2;
+    int total = 0;
+    int max_depth = 0;
+
+    Builder(std::vector<agpt_bvh_node>& n, int mp) : nodes(n), max_prims(mp) {}
+
+    static int bucket_of(const Box& cb, const BuildPrim& p, int axis) {
+        int b = (int)(kBuckets * cb.offset(p.c[axis], axis));
+        if (b == kBuckets) b = kBuckets - 1;
+        return b;
+    }
+
+    void leaf(int slot, int start, int n, const Box& b, int depth) {
+        agpt_bvh_node& nd = nodes[slot];
+        std::memcpy(nd.bmin, b.lo, 12);
+        std::memcpy(nd.bmax, b.hi, 12);
+        nd.first = start;
+        nd.count = n;
+        max_depth = std::max(max_depth, depth);
+    }
+
+    void build(int start, int end, int slot, int depth) {
+        total++;
+        Box bounds;
+        for (int i = start; i < end; i++) bounds.grow(prims[i].box);
+        const int n = end - start;
+        if (n == 1) return leaf(slot, start, n, bounds, depth);
+
+        Box cb;
+        for (int i = start; i < end; i++) cb.grow(V3(prims[i].c[0], prims[i].c[1], prims[i].c[2]));
+        const int axis = cb.longest_axis();
+        if (cb.lo[axis] == cb.hi[axis]) return leaf(slot, start, n, bounds, depth);
+
+        int mid = (start + end) / 2;
+        if (n <= 2) {
+            std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end,
+                             [axis](const BuildPrim& a, const BuildPrim& b) { return a.c[axis] < b.c[axis]; });
+        } else {
+            int count[kBuckets] = {0};
+            Box bb[kBuckets];
+            for (int i = start; i < end; i++) {
+                int b = bucket_of(cb, prims[i], axis);
+                count[b]++;
+                bb[b].grow(prims[i].box);
+            }
+            float cost[kBuckets - 1];
+            for (int i = 0; i < kBuckets - 1; i++) {
+                Box b0, b1;
+                int c0 = 0, c1 = 0;
+                for (int j = 0; j <= i; j++) {
+                    b0.grow(bb[j]);
+                    c0 += count[j];
+                }
+                for (int j = i + 1; j < kBuckets; j++) {
+                    b1.grow(bb[j]);
+                    c1 += count[j];
+                }
+                cost[i] = 1 + (c0 * b0.area() + c1 * b1.area()) / bounds.area();
+            }
+            float min_cost = cost[0];
+            int split = 0;
+            for (int i = 1; i < kBuckets - 1; i++)
+                if (cost[i] < min_cost) {
+                    min_cost = cost[i];
+                    split = i;
+                }
+            const float leaf_cost = (float)n;
+            if (n > max_prims || min_cost < leaf_cost) {
+                BuildPrim* pmid = std::partition(&prims[start], &prims[end - 1] + 1, [&](const BuildPrim& p) {
+                    return bucket_of(cb, p, axis) <= split;
+                });
+                mid = (int)(pmid - &prims[0]);
+            } else {
+                return leaf(slot, start, n, bounds, depth);
+            }
+        }
+        const int first = next_pair;
+        next_pair += 2;
+        build(start, mid, first, depth + 1);
+        build(mid, end, first + 1, depth + 1);
+        agpt_bvh_node& nd = nodes[slot];  // Bounds::Union of the children (bvhtrimesh.h:113-118)
+        for (int a = 0; a < 3; a++) {
+            nd.bmin[a] = tminf(nodes[first].bmin[a], nodes[first + 1].bmin[a]);
+            nd.bmax[a] = tmaxf(nodes[first].bmax[a], nodes[first + 1].bmax[a]);
+        }
+        nd.first = first;
+        nd.count = 0;
+    }
+};
+
+}  // namespace
+
+void build_bvh(HostMesh& mesh, int max_prims_in_node) {
+    const int n_tris = (int)mesh.indices.size() / 9;
+    mesh.nodes.assign((size_t)2 * n_tris + 2, agpt_bvh_node{});
+    Builder b(mesh.nodes, max_prims_in_node);
+    b.prims.resize(n_tris);
+    for (int t = 0; t < n_tris; t++) {
+        BuildPrim& p = b.prims[t];
+        p.index = 3 * t;
+        for (int k = 0; k < 3; k++) p.box.grow(mesh.vertices[mesh.indices[9 * t + 3 * k]]);
+        for (int a = 0; a < 3; a++) p.c[a] = (p.box.lo[a] + p.box.hi[a]) * 0.5f;
+    }
+    b.build(0, n_tris, 0, 0);
+    mesh.total_nodes = b.total;
+    mesh.max_depth = b.max_depth;
+    mesh.nodes.resize((size_t)b.total + 1);
+    mesh.prim_index.resize(n_tris);
+    for (int t = 0; t < n_tris; t++) mesh.prim_index[t] = b.prims[t].index;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+DevMaterial make_material(int type, const float color[3], float roughness, float metallic) {
+    DevMaterial m;
+    std::memset(&m, 0, sizeof(m));
+    m.type = type;
+    const v3 c = V3(color[0], color[1], color[2]);
+    if (type == AGPT_MAT_DISNEY) {
+        // material.h:14-49
+        const float eta = 1.5f;
+        const float strans = 0.f;
+        const float diffuse_weight = (1 - metallic) * (1 - strans);
+        if (diffuse_weight > 0) {
+            m.has_diffuse = 1;
+            m.has_retro = 1;
+            v3 d = diffuse_weight * c;
+            m.diffuse_R[0] = d.x;
+            m.diffuse_R[1] = d.y;
+            m.diffuse_R[2] = d.z;
+        }
+        m.roughness = roughness;
+        const float aspect = 1.f;
+        float ax = smaxf(.001f, (roughness * roughness) / aspect);
+        float ay = smaxf(.001f, (roughness * roughness) * aspect);
+        m.alphax = smaxf(0.001f, ax);  // TrowbridgeReitzDistribution ctor, microfacet.h:120-122
+        m.alphay = smaxf(0.001f, ay);
+        const float spec_tint = 0.f;
+        const v3 ctint = V3s(1.f);
+        const float r0 = ((eta - 1) * (eta - 1)) / ((eta + 1) * (eta + 1));  // SchlickR0FromEta, disney.h:23
+        v3 cspec0 = lerp3(metallic, r0 * lerp3(spec_tint, V3s(1.f), ctint), c);
+        m.R0[0] = cspec0.x;
+        m.R0[1] = cspec0.y;
+        m.R0[2] = cspec0.z;
+        m.metallic = metallic;
+        m.eta = eta;
+        m.has_microfacet = 1;
+    } else if (type == AGPT_MAT_MIRROR) {
+        m.has_specular = 1;
+        m.mirror_R[0] = c.x;
+        m.mirror_R[1] = c.y;
+        m.mirror_R[2] = c.z;
+    } else {
+        m.has_diffuse = 1;
+        m.diffuse_R[0] = c.x;
+        m.diffuse_R[1] = c.y;
+        m.diffuse_R[2] = c.z;
+    }
+    return m;
+}
+
+DevCamera make_camera(const agpt_camera_desc& d) {
+    DevCamera c;
+    const v3 lookfrom = V3(d.lookfrom[0], d.lookfrom[1], d.lookfrom[2]);
+    const v3 lookat = V3(d.lookat[0], d.lookat[1], d.lookat[2]);
+    const v3 vup = V3(d.vup[0], d.vup[1], d.vup[2]);
+    const float theta = d.vfov * AGPT_PI / 180.0f;
+    const float h = tanf(theta / 2);
+    const float viewport_height = 2 * h;
+    const float viewport_width = d.aspect_ratio * viewport_height;
+    c.lens_radius = d.aperture / 2;
+    const float focus_dist = length(lookat - lookfrom);
+    c.w = normalize(lookfrom - lookat);
+    c.u = normalize(cross(vup, c.w));
+    c.v = cross(c.w, c.u);
+    c.origin = lookfrom;
+    c.horizontal = focus_dist * viewport_width * c.u;
+    c.vertical = focus_dist * viewport_height * c.v;
+    c.lower_left_corner = c.origin - c.horizontal / 2 - c.vertical / 2 - focus_dist * c.w;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static inline float4 F4(float x, float y, float z, float w) {
+    float4 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    r.w = w;
+    return r;
+}
+static inline float bits(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSphere>& spheres,
+                   const std::vector<HostPrim>& prims, FlatScene& out) {
+    out.nodes.clear();
+    out.tri_verts.clear();
+    out.tri_shade.clear();
+    out.prims.clear();
+    out.max_depth = 0;
+    size_t node_base = 0, tri_base = 0;
+    std::vector<size_t> mesh_node_base(meshes.size()), mesh_tri_base(meshes.size());
+    for (size_t m = 0; m < meshes.size(); m++) {
+        mesh_node_base[m] = node_base;
+        mesh_tri_base[m] = tri_base;
+        size_t nn = meshes[m].nodes.size();
+        nn = (nn + 1) & ~size_t(1);  // keep every mesh's child pairs 64-B aligned
+        node_base += nn;
+        tri_base += meshes[m].prim_index.size();
+    }
+    out.nodes.assign(2 * node_base, F4(0, 0, 0, 0));
+    out.tri_verts.resize(3 * tri_base);
+    out.tri_shade.resize(4 * tri_base);
+
+    for (size_t pi = 0; pi < prims.size(); pi++) {
+        const HostPrim& hp = prims[pi];
+        DevPrim dp;
+        std::memset(&dp, 0, sizeof(dp));
+        dp.type = hp.type;
+        dp.material = hp.material;
+        dp.arealight = hp.arealight;
+        if (hp.type == AGPT_PRIM_SPHERE) {
+            const HostSphere& s = spheres[hp.index];
+            dp.cx = s.center.x;
+            dp.cy = s.center.y;
+            dp.cz = s.center.z;
+            dp.r = s.r;
+            dp.r2 = s.r2;
+            out.prims.push_back(dp);
+            continue;
+        }
+        const HostMesh& mesh = meshes[hp.index];
+        const size_t nb = mesh_node_base[hp.index], tb = mesh_tri_base[hp.index];
+        const int n_tris = (int)mesh.prim_index.size();
+        dp.root = (int32_t)nb;
+        dp.tri_base = (int32_t)tb;
+        dp.n_tris = n_tris;
+        dp.has_normals = mesh.normals.empty() ? 0 : 1;
+        out.max_depth = std::max(out.max_depth, mesh.max_depth);
+        // nodes: rebase `first` to global node / slot indices
+        for (size_t i = 0; i < mesh.nodes.size(); i++) {
+            if (i == 1) continue;  // unused slot
+            const agpt_bvh_node& n = mesh.nodes[i];
+            uint32_t first = (uint32_t)n.first + (uint32_t)(n.count > 0 ? tb : nb);
+            out.nodes[2 * (nb + i)] = F4(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0]);
+            out.nodes[2 * (nb + i) + 1] = F4(n.bmax[1], n.bmax[2], bits(first), bits((uint32_t)n.count));
+        }
+        {
+            const agpt_bvh_node& r = mesh.nodes[0];
+            std::memcpy(dp.root_bmin, r.bmin, 12);
+            std::memcpy(dp.root_bmax, r.bmax, 12);
+            uint32_t first = (uint32_t)r.first + (uint32_t)(r.count > 0 ? tb : nb);
+            if (r.count == 0)
+                dp.root_enc = first;
+            else if (r.count <= 7 && first < 0x10000000u)
+                dp.root_enc = AGPT_ENC_LEAF | ((uint32_t)(r.count - 1) << 28) | first;
+            else
+                dp.root_enc = AGPT_ENC_BIGLEAF | (uint32_t)nb;
+        }
+        // triangles
+        const bool has_uv = !mesh.texcoords.empty();
+        std::vector<uint32_t> reject(n_tris, 0);
+        for (int t = 0; t < n_tris; t++) {
+            const int32_t* ix = &mesh.indices[9 * t];
+            const v3 v0 = mesh.vertices[ix[0]], v1 = mesh.vertices[ix[3]], v2 = mesh.vertices[ix[6]];
+            // trianglemesh.cpp:46-80 -- ray-independent: uv deltas, dpdu/dpdv, degenerate handling
+            uv_t uv0, uv1, uv2;
+            if (has_uv) {
+                uv0 = mesh.texcoords[ix[2]];
+                uv1 = mesh.texcoords[ix[5]];
+                uv2 = mesh.texcoords[ix[8]];
+            } else {
+                uv0.x = 0; uv0.y = 0;
+                uv1.x = 1; uv1.y = 0;
+                uv2.x = 1; uv2.y = 1;
+            }
+            const float du02x = uv0.x - uv2.x, du02y = uv0.y - uv2.y;
+            const float du12x = uv1.x - uv2.x, du12y = uv1.y - uv2.y;
+            const v3 dp02 = v0 - v2, dp12 = v1 - v2;
+            const float determinant = du02x * du12y - du02y * du12x;
+            const bool degenerate_uv = (double)fabsf(determinant) < 1e-8;
+            v3 dpdu = V3s(0), dpdv = V3s(0);
+            if (!degenerate_uv) {
+                const float invdet = 1 / determinant;
+                dpdu = (du12y * dp02 - du02y * dp12) * invdet;
+                dpdv = (-du12x * dp02 + du02x * dp12) * invdet;
+            }
+            if (degenerate_uv || sqrlen(cross(dpdu, dpdv)) == 0) {
+                v3 ng = cross(v2 - v0, v1 - v0);
+                if (sqrlen(ng) == 0) {
+                    reject[t] = AGPT_TRI_FLAG_REJECT;
+                    dpdu = V3(1, 0, 0);
+                    dpdv = V3(0, 1, 0);
+                } else {
+                    coordinate_system(normalize(ng), &dpdu, &dpdv);
+                }
+            }
+            const v3 ng = normalize(cross(dpdu, dpdv));  // SurfaceInteraction ctor, intersectable.h:69
+            const v3 ss = normalize(dpdu);                // BSDF::ss (reflection.cpp:10) and trianglemesh.cpp:100
+            v3 n0 = V3s(0), n1 = V3s(0), n2 = V3s(0);
+            if (dp.has_normals) {
+                n0 = mesh.normals[ix[1]];
+                n1 = mesh.normals[ix[4]];
+                n2 = mesh.normals[ix[7]];
+            }
+            float4* q = &out.tri_shade[4 * (tb + t)];
+            q[0] = F4(ng.x, ng.y, ng.z, ss.x);
+            q[1] = F4(ss.y, ss.z, n0.x, n0.y);
+            q[2] = F4(n0.z, n1.x, n1.y, n1.z);
+            q[3] = F4(n2.x, n2.y, n2.z, bits((uint32_t)pi));
+        }
+        for (int s = 0; s < n_tris; s++) {
+            const int t = mesh.prim_index[s] / 3;
+            const int32_t* ix = &mesh.indices[9 * t];
+            const v3 v0 = mesh.vertices[ix[0]], v1 = mesh.vertices[ix[3]], v2 = mesh.vertices[ix[6]];
+            float4* q = &out.tri_verts[3 * (tb + s)];
+            q[0] = F4(v0.x, v0.y, v0.z, bits((uint32_t)(tb + t)));
+            q[1] = F4(v1.x, v1.y, v1.z, bits(reject[t]));
+            q[2] = F4(v2.x, v2.y, v2.z, 0.f);
+        }
+        out.prims.push_back(dp);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+void create_backdrop(v3 origin, v3 size, float radius, int steps, std::vector<v3>& vertices, std::vector<v3>& normals,
+                     std::vector<v2>& texcoords, std::vector<int32_t>& indices) {
+    const float width = size.x, height = size.y, depth = size.z;
+    auto push = [&](v3 p, v3 n, float u, float v) {
+        vertices.push_back(p);
+        normals.push_back(n);
+        v2 t;
+        t.x = u;
+        t.y = v;
+        texcoords.push_back(t);
+    };
+    push(origin + V3(width / 2, height, 0), V3(0, 0, -1), 0, 0);
+    push(origin + V3(-width / 2, height, 0), V3(0, 0, -1), 0, 1);
+    push(origin + V3(width / 2, radius * 1.1f, 0), V3(0, 0, -1), 1, 0);
+    push(origin + V3(-width / 2, radius * 1.1f, 0), V3(0, 0, -1), 1, 1);
+    const float step_angle = AGPT_PI / (2 * steps);
+    for (int i = 0; i <= steps; i++) {
+        const float z_rot = cosf(step_angle * i);
+        const float y_rot = -sinf(step_angle * i);
+        const v3 n = normalize(V3(0, -y_rot, -z_rot));
+        push(origin + V3(width / 2, y_rot * radius + radius, z_rot * radius - radius), n, 2.f + i, 0);
+        push(origin + V3(-width / 2, y_rot * radius + radius, z_rot * radius - radius), n, 2.f + i, 1);
+    }
+    push(origin + V3(width / 2, 0, -radius * 1.1f), V3(0, 1, 0), 3.f + steps, 0);
+    push(origin + V3(-width / 2, 0, -radius * 1.1f), V3(0, 1, 0), 3.f + steps, 1);
+    push(origin + V3(width / 2, 0, -depth), V3(0, 1, 0), 4.f + steps, 0);
+    push(origin + V3(-width / 2, 0, -depth), V3(0, 1, 0), 4.f + steps, 1);
+    auto idx = [&](int i) {
+        indices.push_back(i);
+        indices.push_back(i);
+        indices.push_back(i);
+    };
+    const int parts = 4 + steps;
+    for (int i = 0; i < parts; i++) {
+        idx(i * 2);
+        idx((i + 1) * 2);
+        idx(i * 2 + 1);
+        idx((i + 1) * 2);
+        idx((i + 1) * 2 + 1);
+        idx(i * 2 + 1);
+    }
+}
+
+}  // namespace agpt

@@ -1,0 +1,68 @@
+// agpt_host_scene.hpp -- host-side scene container behind the C ABI: keeps what the reference's Scene /
+// BVHTriMesh / Sphere / Material / Light objects hold (scene.h, bvhtrimesh.h, intersectable.h, material.h,
+// lights.h) as flat arrays, builds the binned-SAH BVH on the host and flattens everything into the
+// HBM layout of agpt_scene.h.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/agpt.h"
+#include "agpt_scene.h"
+
+namespace agpt {
+
+struct HostMesh {
+    std::vector<v3> vertices, normals;
+    std::vector<v2> texcoords;
+    std::vector<int32_t> indices;  // (v, n, t) triplets
+    int material = -1;
+    // BVH in the reference layout (bvhtrimesh.h:126-130, 312-330); nodes[1] is the unused slot
+    std::vector<agpt_bvh_node> nodes;
+    int total_nodes = 0;
+    std::vector<int32_t> prim_index;  // reordered Primitive::index (= 3 * triangle)
+    int max_depth = 0;
+};
+
+struct HostSphere {
+    v3 center;
+    float r, r2;
+};
+
+struct HostPrim {
+    int type;
+    int index;  // into meshes / spheres
+    int material;
+    int arealight;
+};
+
+struct HostLight {
+    int type;
+    int shape;
+    v3 L;
+};
+
+// BVHTriMesh ctor: Primitive list + BuildRecursive + FlattenBVHTree (bvhtrimesh.h:154-178,213-330)
+void build_bvh(HostMesh& mesh, int max_prims_in_node);
+
+// DisneyMaterial / MirrorMaterial ctor parameterisation (material.h:14-49,72-77)
+DevMaterial make_material(int type, const float color[3], float roughness, float metallic);
+
+// Camera ctor + updateCoords (camera.h:38-56,77-90)
+DevCamera make_camera(const agpt_camera_desc& d);
+
+struct FlatScene {
+    std::vector<float4> nodes, tri_verts, tri_shade;
+    std::vector<DevPrim> prims;
+    int max_depth = 0;
+};
+// per-mesh concatenation + per-triangle precomputation (trianglemesh.cpp:46-111's ray-independent part)
+void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSphere>& spheres,
+                   const std::vector<HostPrim>& prims, FlatScene& out);
+
+// TriangleMesh::CreateBackdrop (trianglemesh.cpp:232-318)
+void create_backdrop(v3 origin, v3 size, float radius, int steps, std::vector<v3>& vertices, std::vector<v3>& normals,
+                     std::vector<v2>& texcoords, std::vector<int32_t>& indices);
+
+}  // namespace agpt

@@ -1,0 +1,512 @@
+// agpt_kernels.h -- the gfx950 kernels of the wavefront path tracer.
+//
+// One agpt_render batch = S samples x NP tile pixels paths, path id = s*NP + p.  Per iteration:
+//     k_trace<closest>(ext queue)   continuation rays            -> hit[]
+//     k_trace<closest>(mis queue)   BSDF-sampled MIS rays        -> mis_hit[]
+//     k_trace<any>(shadow queue)    NEE shadow rays              -> occluded[]
+//     k_shade(active queue)         resolves the previous vertex' NEE, then PathTracer::Li's loop body for the
+//                                   new hit; appends to the next iteration's queues with one wave-aggregated
+//                                   atomic per queue per wave (ballot + prefix popcount compaction)
+// The trace kernels are persistent: a fixed grid of waves pulls 64-ray chunks off the queue with one atomic per
+// chunk; queue lengths stay on the device (no host round trip per iteration).  Path state is SoA float4 in HBM
+// (coalesced 16 B/lane); the per-lane traversal stack lives in LDS (32 entries x 4 B x 256 lanes = 32 KiB/block).
+#pragma once
+
+#include "agpt_shade.h"
+#include "agpt_trace.h"
+
+#define AGPT_BLOCK 256
+#define AGPT_CHUNK 64
+
+// path flags (beta4.w)
+#define PF_BOUNCE_MASK 0xFFu
+#define PF_SPECULAR 0x100u   // specularBounce
+#define PF_DEAD 0x200u       // path ended; only the pending NEE of its last vertex is left to resolve
+#define PF_PEND_C1 0x400u    // light-sampling leg contribution waits for its shadow ray
+#define PF_PEND_C2 0x800u    // BSDF-sampling leg contribution waits for its MIS ray
+#define PF_PENDING 0x1000u   // a vertex' UniformSampleOneLight result is still to be added to L
+
+struct PathBuffers {
+    float4 *ext_o, *ext_d;        // continuation ray (o.w = tmax)
+    float4 *sh_o, *sh_d;          // shadow ray
+    float4 *mis_o, *mis_d;        // MIS ray
+    DevHit *hit, *mis_hit;
+    uint32_t* occluded;
+    float4* beta4;                // beta.xyz, flags
+    float4* L4;                   // L.xyz, rng state
+    float4* fac4;                 // f*|wi.ns|/pdf of the sampled continuation, chosen light index
+    float4 *c1, *c2;              // pending NEE contributions (light leg / BSDF leg)
+};
+
+struct Queues {
+    uint32_t *active, *ext, *mis, *shadow;   // path ids
+    uint32_t* counts;                        // [0]=active [1]=ext [2]=mis [3]=shadow
+};
+
+struct RenderConsts {
+    int32_t W, H, x0, y0, w, h;
+    int32_t s0, S;            // first sample index of the batch, samples in the batch
+    uint32_t seed_base;
+    int32_t max_depth;
+    int32_t accum_pitch, accum_row0;
+    uint32_t NP;              // w*h
+};
+
+struct DevCounters {
+    unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// wave-aggregated queue append: one atomic per wave, order inside the wave preserved
+__device__ __forceinline__ void queue_push(uint32_t* q, uint32_t* count, bool pred, uint32_t value) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    int lane = __lane_id();
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (pred) {
+        uint32_t off = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        q[base + off] = value;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+        uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+        DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters) {
+    __shared__ uint32_t s_stack[AGPT_STACK_DEPTH * AGPT_BLOCK];
+    uint32_t* stack = s_stack + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t count = count_ptr ? *count_ptr : count_imm;
+    TraceCounters cnt;
+    cnt.interior = 0;
+    cnt.tris = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(work_head, (uint32_t)AGPT_CHUNK);
+        base = __shfl(base, 0);
+        if (base >= count) break;
+        uint32_t i = base + lane;
+        if (i < count) {
+            uint32_t pid = queue ? queue[i] : i;
+            float4 o = ray_o[pid], d = ray_d[pid];
+            DevHit h;
+            bool hit = trace_scene<ANY, COUNT>(sc, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, h, stack, AGPT_BLOCK, cnt);
+            if (ANY)
+                occluded[pid] = hit ? 1u : 0u;
+            else
+                hits[pid] = h;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters->interior, (unsigned long long)cnt.interior);
+        atomicAdd(&counters->tris, (unsigned long long)cnt.tris);
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (ANY)
+            atomicAdd(&counters->anyhit_rays, (unsigned long long)count);
+        else
+            atomicAdd(&counters->closest_rays, (unsigned long long)count);
+    }
+}
+
+// agpt_intersect_batch: Ray ctor (camera.h:6) normalises D
+__global__ void k_prepare_rays(const agpt_ray* __restrict__ in, int n, float4* __restrict__ ray_o, float4* __restrict__ ray_d) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    agpt_ray r = in[i];
+    v3 d = normalize(V3(r.d[0], r.d[1], r.d[2]));
+    float4 o4, d4;
+    o4.x = r.o[0]; o4.y = r.o[1]; o4.z = r.o[2]; o4.w = r.tmax;
+    d4.x = d.x; d4.y = d.y; d4.z = d.z; d4.w = 0.f;
+    ray_o[i] = o4;
+    ray_d[i] = d4;
+}
+__global__ void k_export_hits(const DevScene sc, const DevHit* __restrict__ hits, const uint32_t* __restrict__ occluded,
+                              int n, int any_hit, agpt_hit* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    agpt_hit o;
+    o.hit = 0; o.prim = -1; o.tri = -1; o.t = 0; o.b1 = 0; o.b2 = 0;
+    if (any_hit) {
+        o.hit = occluded[i] ? 1 : 0;
+    } else {
+        DevHit h = hits[i];
+        if (h.id != AGPT_HIT_MISS) {
+            o.hit = 1;
+            o.t = h.t;
+            if (h.id & AGPT_HIT_SPHERE) {
+                o.prim = (int)(h.id & 0x7FFFFFFFu);
+            } else {
+                int prim = (int)__float_as_uint(sc.tri_shade[4 * (size_t)h.id + 3].w);
+                o.prim = prim;
+                o.tri = 3 * ((int)h.id - sc.prims[prim].tri_base);
+                o.b1 = h.b1;
+                o.b2 = h.b2;
+            }
+        }
+    }
+    out[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// myapp.cpp:165-167: jittered film position -> Camera::GetRay (camera.h:58-64; lens: common.h:65-71)
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t total = rc.NP * (uint32_t)rc.S;
+    if (i >= total) return;
+    uint32_t sl = i / rc.NP, p = i - sl * rc.NP;
+    int x = rc.x0 + (int)(p % (uint32_t)rc.w), y = rc.y0 + (int)(p / (uint32_t)rc.w);
+    uint32_t rng = sample_seed((uint32_t)(y * rc.W + x), (uint32_t)(rc.W * rc.H), (uint32_t)(rc.s0 + (int)sl), rc.seed_base);
+    float px = x + rng_float(rng);
+    float py = y + rng_float(rng);
+    float s = px / rc.W, t = py / rc.H;
+    const DevCamera& c = sc.cam;
+    v3 rd = V3s(0.f);
+    if (c.lens_radius > 0.f) {
+        for (;;) {
+            float a = -1.f + (1.f - -1.f) * rng_float(rng);
+            float b = -1.f + (1.f - -1.f) * rng_float(rng);
+            v3 pd = V3(a, b, 0);
+            if (sqrlen(pd) >= 1) continue;
+            rd = c.lens_radius * pd;
+            break;
+        }
+    }
+    v3 offset = c.u * rd.x + c.v * rd.y;
+    v3 pixel = c.lower_left_corner + s * c.horizontal + t * c.vertical;
+    v3 O = c.origin + offset;
+    v3 D = normalize(pixel - c.origin - offset);
+    float4 o4, d4, b4, l4;
+    o4.x = O.x; o4.y = O.y; o4.z = O.z; o4.w = AGPT_FLT_MAX;
+    d4.x = D.x; d4.y = D.y; d4.z = D.z; d4.w = 0.f;
+    b4.x = 1.f; b4.y = 1.f; b4.z = 1.f; b4.w = __uint_as_float(0u);
+    l4.x = 0.f; l4.y = 0.f; l4.z = 0.f; l4.w = __uint_as_float(rng);
+    pb.ext_o[i] = o4;
+    pb.ext_d[i] = d4;
+    pb.beta4[i] = b4;
+    pb.L4[i] = l4;
+    q.active[i] = i;
+    q.ext[i] = i;
+    if (i == 0) {
+        q.counts[0] = total;
+        q.counts[1] = total;
+        q.counts[2] = 0;
+        q.counts[3] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PathTracer::Li's loop body (integrator.h:132-188) in wavefront form.
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_shade(DevScene sc, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout, DevCounters* __restrict__ counters) {
+    const uint32_t n_active = qin.counts[0];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // all lanes of a wave iterate together so the ballots in queue_push see every lane
+    const uint32_t n_round = (n_active + 63u) & ~63u;
+    uint32_t shaded = 0;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < n_round; qi += stride) {
+        const bool valid = qi < n_active;
+        bool push_active = false, push_ext = false, push_mis = false, push_shadow = false;
+        uint32_t pid = 0;
+        if (valid) {
+            pid = qin.active[qi];
+            float4 b4 = pb.beta4[pid];
+            float4 l4 = pb.L4[pid];
+            v3 beta = V3(b4.x, b4.y, b4.z);
+            v3 L = V3(l4.x, l4.y, l4.z);
+            uint32_t flags = __float_as_uint(b4.w);
+            uint32_t rng = __float_as_uint(l4.w);
+
+            // ---- resolve the previous vertex' UniformSampleOneLight (integrator.h:38-105) ------------------
+            if (flags & PF_PENDING) {
+                float4 f4 = pb.fac4[pid];
+                v3 Ld = V3s(0.f);
+                if (flags & PF_PEND_C1) {
+                    if (!pb.occluded[pid]) {  // VisibilityTester::Unoccluded, lights.cpp:10-12
+                        float4 c = pb.c1[pid];
+                        Ld = Ld + V3(c.x, c.y, c.z);
+                    }
+                }
+                if (flags & PF_PEND_C2) {
+                    uint32_t light = __float_as_uint(f4.w);
+                    uint32_t hid = pb.mis_hit[pid].id;
+                    bool add;
+                    if (hid != AGPT_HIT_MISS) {  // integrator.h:82-85: hit shape's area light must be the sampled light
+                        int hp = (hid & AGPT_HIT_SPHERE) ? (int)(hid & 0x7FFFFFFFu)
+                                                         : (int)__float_as_uint(sc.tri_shade[4 * (size_t)hid + 3].w);
+                        add = sc.prims[hp].arealight == (int)light;
+                    } else {  // :86-87 light.Le(ray): non-zero only for the infinite light
+                        add = sc.lights[light].type == AGPT_LIGHT_UNIFORM_INFINITE;
+                    }
+                    if (add) {
+                        float4 c = pb.c2[pid];
+                        Ld = Ld + V3(c.x, c.y, c.z);
+                    }
+                }
+                float lightPdf = 1.f / sc.n_lights;           // integrator.h:100,104
+                L = L + beta * (Ld / lightPdf);               // integrator.h:166
+                if (!(flags & PF_DEAD)) beta = beta * V3(f4.x, f4.y, f4.z);  // integrator.h:176
+                flags &= ~(PF_PENDING | PF_PEND_C1 | PF_PEND_C2);
+            }
+
+            if (!(flags & PF_DEAD)) {
+                uint32_t bounces = flags & PF_BOUNCE_MASK;
+                DevHit h = pb.hit[pid];
+                float4 o4 = pb.ext_o[pid], d4 = pb.ext_d[pid];
+                v3 O = V3(o4.x, o4.y, o4.z), D = V3(d4.x, d4.y, d4.z);
+                const bool found = h.id != AGPT_HIT_MISS;
+                Surface s;
+                if (found) {
+                    if (h.id & AGPT_HIT_SPHERE)
+                        surface_from_sphere(sc, (int)(h.id & 0x7FFFFFFFu), O, D, h.t, s);
+                    else
+                        surface_from_triangle(sc, h.id, h.b1, h.b2, O, D, h.t, s);
+                }
+                // integrator.h:139-147
+                if (bounces == 0 || (flags & PF_SPECULAR)) {
+                    if (found) {
+                        int al = sc.prims[s.prim].arealight;
+                        v3 Le = al >= 0 ? mat_v3(sc.lights[al].L) : V3s(0.f);
+                        L = L + beta * Le;
+                    } else {
+                        for (int li = 0; li < sc.n_lights; li++)
+                            if (sc.lights[li].type == AGPT_LIGHT_UNIFORM_INFINITE) L = L + beta * mat_v3(sc.lights[li].L);
+                    }
+                }
+                if (!found || (int)bounces >= rc.max_depth) {  // :150
+                    flags |= PF_DEAD;
+                } else if (sc.prims[s.prim].material < 0) {
+                    // :152-161 null material: skip the surface, re-cast without counting a bounce
+                    v3 nO = s.p + AGPT_EPSILON * D;
+                    v3 nD = normalize(D);
+                    float4 no4, nd4;
+                    no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
+                    nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
+                    pb.ext_o[pid] = no4;
+                    pb.ext_d[pid] = nd4;
+                    push_ext = true;
+                } else {
+                    shaded++;
+                    const DevMaterial& m = sc.materials[sc.prims[s.prim].material];
+                    Bsdf bsdf;
+                    bsdf_setup(bsdf, m, s.n, s.ns, s.ss_bsdf);
+                    // ---- UniformSampleOneLight / EstimateDirect (integrator.h:38-105) -------------------
+                    if (!bsdf_is_perfectly_specular(bsdf) && sc.n_lights > 0) {
+                        int nLights = sc.n_lights;
+                        int numLight = (int)(rng_float(rng) * nLights);
+                        if (nLights - 1 < numLight) numLight = nLights - 1;
+                        float uL0 = rng_float(rng), uL1 = rng_float(rng);
+                        float uS0 = rng_float(rng), uS1 = rng_float(rng);
+                        const DevLight& light = sc.lights[numLight];
+                        flags |= PF_PENDING;
+                        v3 wi = V3s(0.f);
+                        float lightPdf = 0, scatteringPdf = 0;
+                        v3 Li;
+                        v3 visO = V3s(0.f), visD = V3(0, 0, 1);
+                        float visT = 0;
+                        if (light.type == AGPT_LIGHT_UNIFORM_INFINITE) {  // lights.cpp:15-24 (quirk 3)
+                            wi = random_in_hemisphere(rng, s.ns);
+                            lightPdf = AGPT_INV2PI;
+                            visO = s.p + AGPT_EPSILON * wi;
+                            visD = normalize(wi);
+                            visT = AGPT_FLT_MAX;
+                            Li = mat_v3(light.L);
+                        } else {  // AreaLight::Sample_Li lights.cpp:115-126
+                            v3 pS;
+                            sphere_sample_ref(sc.prims[light.shape], s.p, uL0, uL1, &pS, &lightPdf);
+                            if (lightPdf == 0 || sqrlen(pS - s.p) == 0) {
+                                lightPdf = 0;
+                                Li = V3s(0.f);
+                            } else {
+                                wi = pS - s.p;
+                                float dist = length(wi);
+                                wi = wi / dist;
+                                visO = s.p + AGPT_EPSILON * wi;
+                                visD = normalize(wi);
+                                visT = dist - 10 * AGPT_EPSILON;
+                                Li = mat_v3(light.L);
+                            }
+                        }
+                        if (lightPdf > 0 && !isblack(Li)) {  // integrator.h:44-60
+                            v3 f = bsdf_f(bsdf, m, s.wo, wi, true) * absdot(wi, s.ns);
+                            scatteringPdf = bsdf_pdf(bsdf, m, s.wo, wi, true);
+                            if (!isblack(f)) {
+                                float weight = power_heuristic(1, lightPdf, 1, scatteringPdf);
+                                v3 c1 = f * Li * weight / lightPdf;
+                                float4 c4, so4, sd4;
+                                c4.x = c1.x; c4.y = c1.y; c4.z = c1.z; c4.w = 0.f;
+                                so4.x = visO.x; so4.y = visO.y; so4.z = visO.z; so4.w = visT;
+                                sd4.x = visD.x; sd4.y = visD.y; sd4.z = visD.z; sd4.w = 0.f;
+                                pb.c1[pid] = c4;
+                                pb.sh_o[pid] = so4;
+                                pb.sh_d[pid] = sd4;
+                                flags |= PF_PEND_C1;
+                                push_shadow = true;
+                            }
+                        }
+                        {  // integrator.h:63-90 BSDF-sampling leg
+                            v3 f = bsdf_sample_f(bsdf, m, s.wo, &wi, uS0, uS1, &scatteringPdf, true, nullptr);
+                            f = f * absdot(wi, s.ns);
+                            if (!isblack(f) && scatteringPdf > 0) {
+                                float lp;
+                                if (light.type == AGPT_LIGHT_UNIFORM_INFINITE)
+                                    lp = dot(s.n, wi) > 0 ? AGPT_INV2PI : 0.f;  // lights.cpp:26-28 (geometric n)
+                                else
+                                    lp = sphere_pdf(sc.prims[light.shape], s.p);
+                                if (lp != 0) {
+                                    float weight = power_heuristic(1, scatteringPdf, 1, lp);
+                                    v3 Li2 = mat_v3(light.L);  // Le(-wi) of the light's shape, or light.Le(ray) on a miss
+                                    if (!isblack(Li2)) {
+                                        v3 c2 = f * Li2 * weight / scatteringPdf;
+                                        v3 mO = s.p + AGPT_EPSILON * wi;
+                                        v3 mD = normalize(wi);
+                                        float4 c4, mo4, md4;
+                                        c4.x = c2.x; c4.y = c2.y; c4.z = c2.z; c4.w = 0.f;
+                                        mo4.x = mO.x; mo4.y = mO.y; mo4.z = mO.z; mo4.w = AGPT_FLT_MAX;
+                                        md4.x = mD.x; md4.y = mD.y; md4.z = mD.z; md4.w = 0.f;
+                                        pb.c2[pid] = c4;
+                                        pb.mis_o[pid] = mo4;
+                                        pb.mis_d[pid] = md4;
+                                        flags |= PF_PEND_C2;
+                                        push_mis = true;
+                                    }
+                                }
+                            }
+                        }
+                        // the chosen light rides in fac4.w
+                        float4 f4;
+                        f4.x = 1.f; f4.y = 1.f; f4.z = 1.f; f4.w = __uint_as_float((uint32_t)numLight);
+                        pb.fac4[pid] = f4;
+                    }
+                    // ---- sample the BSDF for the next direction (integrator.h:170-187) -----------------
+                    v3 wi = V3s(0.f);
+                    float u0 = rng_float(rng), u1 = rng_float(rng);
+                    float pdf = 0;
+                    bool sampledSpecular = false;
+                    v3 f = bsdf_sample_f(bsdf, m, s.wo, &wi, u0, u1, &pdf, false, &sampledSpecular);
+                    if (isblack(f) || pdf == 0) {
+                        flags |= PF_DEAD;
+                    } else {
+                        v3 fac = f * absdot(wi, s.ns) / pdf;
+                        if (flags & PF_PENDING) {
+                            float4 f4 = pb.fac4[pid];
+                            f4.x = fac.x; f4.y = fac.y; f4.z = fac.z;
+                            pb.fac4[pid] = f4;
+                        } else {
+                            beta = beta * fac;
+                        }
+                        flags = (flags & ~PF_SPECULAR) | (sampledSpecular ? PF_SPECULAR : 0u);
+                        flags = (flags & ~PF_BOUNCE_MASK) | ((bounces + 1) & PF_BOUNCE_MASK);
+                        v3 nO = s.p + AGPT_EPSILON * wi;
+                        v3 nD = normalize(wi);
+                        float4 no4, nd4;
+                        no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
+                        nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
+                        pb.ext_o[pid] = no4;
+                        pb.ext_d[pid] = nd4;
+                        push_ext = true;
+                    }
+                }
+            }
+            push_active = push_ext || (flags & PF_PENDING);
+            b4.x = beta.x; b4.y = beta.y; b4.z = beta.z; b4.w = __uint_as_float(flags);
+            l4.x = L.x; l4.y = L.y; l4.z = L.z; l4.w = __uint_as_float(rng);
+            pb.beta4[pid] = b4;
+            pb.L4[pid] = l4;
+        }
+        queue_push(qout.active, &qout.counts[0], push_active, pid);
+        queue_push(qout.ext, &qout.counts[1], push_ext, pid);
+        queue_push(qout.mis, &qout.counts[2], push_mis, pid);
+        queue_push(qout.shadow, &qout.counts[3], push_shadow, pid);
+    }
+    if (shaded) atomicAdd(&counters->shaded, (unsigned long long)shaded);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// myapp.cpp:169-173 NaN/inf reject + Accumulator::AddSample (myapp.h:17-19): samples are added in sample order
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_accumulate(RenderConsts rc, PathBuffers pb, float4* __restrict__ accum, DevCounters* __restrict__ counters) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= rc.NP) return;
+    int x = rc.x0 + (int)(p % (uint32_t)rc.w), y = rc.y0 + (int)(p / (uint32_t)rc.w);
+    size_t ai = (size_t)((rc.H - 1 - y) - rc.accum_row0) * (size_t)rc.accum_pitch + (size_t)x;
+    float4 a = accum[ai];
+    uint32_t bad = 0;
+    for (int s = 0; s < rc.S; s++) {
+        float4 l4 = pb.L4[(size_t)s * rc.NP + p];
+        v3 clr = V3(l4.x, l4.y, l4.z);
+        if (isnan(clr.x) || isnan(clr.y) || isnan(clr.z) || isinf(luminance(clr))) {
+            clr = V3s(0.f);
+            bad++;
+        }
+        a.x += clr.x;
+        a.y += clr.y;
+        a.z += clr.z;
+    }
+    accum[ai] = a;
+    if (bad) atomicAdd(&counters->outliers, (unsigned long long)bad);
+}
+
+// Accumulator::CopyToSurface (myapp.h:34-41) with lin2rgb / rgb2uint (template/common.h:41-51)
+__global__ void k_resolve(const float4* __restrict__ accum, int n, int samples, uint32_t* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = accum[i];
+    float e = 1 / 2.2f;
+    float inv = (float)samples;
+    float r = powf(a.x / inv, e), g = powf(a.y / inv, e), b = powf(a.z / inv, e);
+    int ri = (int)(256 * tclampf(r, 0.0f, 0.999f));
+    int gi = (int)(256 * tclampf(g, 0.0f, 0.999f));
+    int bi = (int)(256 * tclampf(b, 0.0f, 0.999f));
+    out[i] = (uint32_t)((ri << 16) + (gi << 8) + bi);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// known-answer kernels (one lane per case)
+__device__ __forceinline__ void kat_frame(Bsdf& b, const DevMaterial& m) {
+    // canonical SurfaceInteraction: dpdu = +x, dpdv = +y -> n = ns = +z, ss = +x
+    bsdf_setup(b, m, V3(0, 0, 1), V3(0, 0, 1), V3(1, 0, 0));
+}
+__global__ void k_kat_bsdf_eval(DevScene sc, int material, int n, const float* __restrict__ wo3, const float* __restrict__ wi3,
+                                float* __restrict__ f3o, float* __restrict__ pdfo) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevMaterial& m = sc.materials[material];
+    Bsdf b;
+    kat_frame(b, m);
+    v3 wo = V3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi = V3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
+    v3 f = bsdf_f(b, m, wo, wi, true);
+    f3o[3 * i] = f.x; f3o[3 * i + 1] = f.y; f3o[3 * i + 2] = f.z;
+    pdfo[i] = bsdf_pdf(b, m, wo, wi, true);
+}
+__global__ void k_kat_bsdf_sample(DevScene sc, int material, int n, const float* __restrict__ wo3, const float* __restrict__ u2,
+                                  float* __restrict__ wi3o, float* __restrict__ f3o, float* __restrict__ pdfo,
+                                  int32_t* __restrict__ speco) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevMaterial& m = sc.materials[material];
+    Bsdf b;
+    kat_frame(b, m);
+    v3 wo = V3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
+    v3 wi = V3s(0.f);
+    float pdf = 0;
+    bool spec = false;
+    v3 f = bsdf_sample_f(b, m, wo, &wi, u2[2 * i], u2[2 * i + 1], &pdf, false, &spec);
+    wi3o[3 * i] = wi.x; wi3o[3 * i + 1] = wi.y; wi3o[3 * i + 2] = wi.z;
+    f3o[3 * i] = f.x; f3o[3 * i + 1] = f.y; f3o[3 * i + 2] = f.z;
+    pdfo[i] = pdf;
+    speco[i] = spec ? 1 : 0;
+}
+__global__ void k_kat_rng(uint32_t pixel, uint32_t wh, uint32_t sample, uint32_t seed_base, int n, float* __restrict__ out,
+                          uint32_t* __restrict__ seed_out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t s = sample_seed(pixel, wh, sample, seed_base);
+    *seed_out = s;
+    for (int i = 0; i < n; i++) out[i] = rng_float(s);
+}

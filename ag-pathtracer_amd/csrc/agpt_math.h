@@ -1,0 +1,114 @@
+// agpt_math.h -- fp32 vector helpers shared by the host scene builder and the gfx950 kernels.
+//
+// Every expression is written in the operation order the reference uses so that, compiled with
+// -ffp-contract=off (no FMA fusion) and IEEE divide/sqrt, host and device produce the same bits as a
+// strict-IEEE build of the reference's L1 math (template/precomp.h:364-369,671-768; template/common.h).
+// Trigonometric functions are the one implementation-defined ingredient of the reference (it calls the
+// platform libm); here they are defined as the correctly rounded fp32 value, computed through fp64
+// (MI355X runs fp64 vector math at half the fp32 rate, and shading is <3 % of the path).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define AGPT_HD __host__ __device__ __forceinline__
+
+#define AGPT_PI 3.14159265358979323846264f
+#define AGPT_INVPI 0.31830988618379067153777f
+#define AGPT_INV2PI 0.15915494309189533576888f
+#define AGPT_TWOPI 6.28318530717958647692528f
+#define AGPT_EPSILON 0.0001f
+#define AGPT_ONE_MINUS_EPS 0x1.fffffep-1f
+#define AGPT_FLT_MAX 3.402823466e+38f
+
+struct v3 {
+    float x, y, z;
+};
+struct v2 {
+    float x, y;
+};
+
+AGPT_HD v3 V3(float x, float y, float z) {
+    v3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+AGPT_HD v3 V3s(float s) { return V3(s, s, s); }
+AGPT_HD v3 operator+(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+AGPT_HD v3 operator-(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+AGPT_HD v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
+AGPT_HD v3 operator*(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+AGPT_HD v3 operator*(v3 a, float b) { return V3(a.x * b, a.y * b, a.z * b); }
+AGPT_HD v3 operator*(float b, v3 a) { return V3(b * a.x, b * a.y, b * a.z); }
+AGPT_HD v3 operator/(v3 a, float b) { return V3(a.x / b, a.y / b, a.z / b); }
+
+// template/precomp.h:364-365: comparators, not libm fminf/fmaxf
+AGPT_HD float tminf(float a, float b) { return a < b ? a : b; }
+AGPT_HD float tmaxf(float a, float b) { return a > b ? a : b; }
+// std::min / std::max
+AGPT_HD float sminf(float a, float b) { return (b < a) ? b : a; }
+AGPT_HD float smaxf(float a, float b) { return (a < b) ? b : a; }
+AGPT_HD float tclampf(float f, float a, float b) { return tmaxf(a, tminf(f, b)); }
+
+AGPT_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+AGPT_HD float absdot(v3 a, v3 b) { return fabsf(dot(a, b)); }
+AGPT_HD float sqrlen(v3 a) { return dot(a, a); }
+AGPT_HD float length(v3 a) { return sqrtf(dot(a, a)); }
+AGPT_HD v3 cross(v3 a, v3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+AGPT_HD v3 normalize(v3 v) {
+    float invLen = 1.0f / sqrtf(dot(v, v));
+    return v * invLen;
+}
+AGPT_HD v3 faceforward(v3 v, v3 v2) { return (dot(v, v2) < 0.f) ? -v : v; }
+AGPT_HD bool isblack(v3 v) { return v.x == 0 && v.y == 0 && v.z == 0; }
+AGPT_HD v3 lerp3(float t, v3 s1, v3 s2) { return (1 - t) * s1 + t * s2; }
+AGPT_HD v3 reflect3(v3 wo, v3 n) { return -wo + 2.0f * dot(wo, n) * n; }
+AGPT_HD bool same_hemisphere(v3 w, v3 wp) { return w.z * wp.z > 0; }
+AGPT_HD float luminance(v3 v) { return 0.212671f * v.x + 0.715160f * v.y + 0.072169f * v.z; }
+AGPT_HD float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// correctly rounded fp32 trig through fp64
+AGPT_HD float cr_sinf(float x) { return (float)sin((double)x); }
+AGPT_HD float cr_cosf(float x) { return (float)cos((double)x); }
+AGPT_HD float cr_acosf(float x) { return (float)acos((double)x); }
+AGPT_HD void cr_sincosf(float x, float* s, float* c) {
+    double ds, dc;
+    sincos((double)x, &ds, &dc);
+    *s = (float)ds;
+    *c = (float)dc;
+}
+
+// template/common.h:145-151
+AGPT_HD void coordinate_system(v3 v1, v3* v2, v3* v3o) {
+    if (fabsf(v1.x) > fabsf(v1.y))
+        *v2 = V3(-v1.z, 0, v1.x) / sqrtf(v1.x * v1.x + v1.z * v1.z);
+    else
+        *v2 = V3(0, v1.z, -v1.y) / sqrtf(v1.y * v1.y + v1.z * v1.z);
+    *v3o = cross(v1, *v2);
+}
+
+// RNG: template/template.cpp:667-675 (xorshift32) seeded per (pixel, sample) as cl/tools.cl:1-2 prescribes
+AGPT_HD uint32_t wang_hash(uint32_t s) {
+    s = (s ^ 61) ^ (s >> 16);
+    s *= 9;
+    s = s ^ (s >> 4);
+    s *= 0x27d4eb2d;
+    s = s ^ (s >> 15);
+    return s;
+}
+AGPT_HD uint32_t sample_seed(uint32_t pixel, uint32_t wh, uint32_t sample, uint32_t seed_base) {
+    uint32_t idx = pixel + wh * sample;
+    uint32_t s = wang_hash((idx + 1u) * 17u + seed_base);
+    if (s == 0) s = 0x12345678u;
+    return s;
+}
+AGPT_HD uint32_t rng_uint(uint32_t& s) {
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return s;
+}
+AGPT_HD float rng_float(uint32_t& s) { return rng_uint(s) * 2.3283064365387e-10f; }

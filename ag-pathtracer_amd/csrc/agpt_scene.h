@@ -1,0 +1,90 @@
+// agpt_scene.h -- flat, HBM-resident scene representation shared by the host builder and the kernels.
+//
+// Layout (all arrays 64-B aligned, replicated per GPU):
+//   nodes      float4[2*N]  reference BVHNode layout (bvhtrimesh.h:126-130): {bmin.xyz,bmax.x}{bmax.yz,first,count};
+//                           sibling pairs share a 64-B line; all meshes concatenated, `first` rebased to global
+//                           node / triangle-slot indices
+//   tri_verts  float4[3*T]  per REORDERED primitive slot (BVH leaf order): v0,v1,v2; v0.w = global triangle id,
+//                           v1.w = flags (bit0: degenerate-reject, quirk 11), v2.w unused.  Replaces the reference's
+//                           primitives[] -> indices[] -> vertices[] double indirection (88 B/test -> 48 B/test)
+//   tri_shade  float4[4*T]  per global triangle id, ray-independent parts of the SurfaceInteraction the reference
+//                           rebuilds on every accepted hit (trianglemesh.cpp:46-111): geometric normal ng,
+//                           ss = normalize(dpdu), the three vertex normals, owning primitive
+//   prims      DevPrim[P]   Scene::primitives in insertion order (scene.h:5-19 walks them linearly)
+//   materials  DevMaterial[M], lights DevLight[L]
+#pragma once
+
+#include "agpt_math.h"
+
+#define AGPT_PRIM_MESH 0
+#define AGPT_PRIM_SPHERE 1
+#define AGPT_LIGHT_AREA 0
+#define AGPT_LIGHT_UNIFORM_INFINITE 1
+
+#define AGPT_HIT_MISS 0xFFFFFFFFu
+#define AGPT_HIT_SPHERE 0x80000000u
+
+#define AGPT_TRI_FLAG_REJECT 1u     // degenerate triangle: TriangleIntersect returns false after the t test
+#define AGPT_STACK_DEPTH 32         // per-lane traversal stack entries staged in LDS
+
+// traversal-stack / node encoding: bit31 = leaf.  leaf with count<=7: bits 28..30 = count-1, bits 0..27 = first slot.
+// leaf with more prims (identical centroids, bvhtrimesh.h:235-238): 0xF0000000 | node index (node is re-fetched).
+#define AGPT_ENC_LEAF 0x80000000u
+#define AGPT_ENC_BIGLEAF 0xF0000000u
+
+struct DevPrim {
+    int32_t type;
+    int32_t material;   // -1 = nullptr (emitter spheres)
+    int32_t arealight;  // index into lights, -1 = none
+    int32_t root;       // mesh: global index of the root node
+    int32_t tri_base;   // mesh: global id of its first triangle
+    int32_t has_normals;
+    int32_t n_tris;
+    int32_t pad0;
+    float cx, cy, cz, r;  // sphere (intersectable.h:161-162)
+    float r2;
+    float root_bmin[3];   // mesh root bounds (bvhtrimesh.h:185-198 tests them before descending)
+    float root_bmax[3];
+    uint32_t root_enc;    // encoded root node
+};
+
+struct DevMaterial {
+    int32_t type;
+    int32_t has_diffuse, has_retro, has_microfacet, has_specular;
+    float diffuse_R[3];  // diffuseWeight * color
+    float roughness;
+    float alphax, alphay;
+    float R0[3];         // Cspec0
+    float metallic, eta;
+    float mirror_R[3];
+};
+
+struct DevLight {
+    int32_t type;
+    int32_t shape;  // primitive index of the emitting sphere
+    float L[3];
+};
+
+struct DevCamera {
+    v3 origin, u, v, w, lower_left_corner, horizontal, vertical;
+    float lens_radius;
+};
+
+struct DevScene {
+    const float4* nodes;
+    const float4* tri_verts;
+    const float4* tri_shade;
+    const DevPrim* prims;
+    const DevMaterial* materials;
+    const DevLight* lights;
+    int32_t n_prims, n_lights, n_materials;
+    int32_t n_infinite;        // number of IsInfinite() lights
+    DevCamera cam;
+};
+
+// 16-B hit record written by the trace kernel
+struct DevHit {
+    float t;
+    uint32_t id;  // AGPT_HIT_MISS | AGPT_HIT_SPHERE|prim | global triangle id
+    float b1, b2;
+};

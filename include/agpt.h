@@ -1,0 +1,181 @@
+/* include/agpt.h -- C ABI of libagpt_hip.so, the MI355X (gfx950) path-tracing hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  The reference has no
+ * FFI -- its seam is three in-process C++ abstract classes:
+ *     Intersectable  intersectable.h:17-61      Scene  scene.h:3-30      Integrator  integrator.h:28-31
+ * and the caller is the per-pixel loop of MyApp::Tick (myapp.cpp:163-175).  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference checkout); the C++
+ * adapter classes that keep reference-style host code unchanged are in include/agpt_host.hpp and the
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: every function returns AGPT_OK (0) or a negative agpt_status and records a message
+ * retrievable with agpt_last_error().  The caller owns host buffers; the library owns device memory
+ * except where a parameter is documented as a DEVICE pointer.  One context per GPU/process; calls on
+ * one context are serialised by the caller.  All arithmetic is fp32, indices int32.
+ */
+#ifndef AGPT_H
+#define AGPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    AGPT_OK = 0,
+    AGPT_ERR_INVALID = -1,   /* bad argument / call order */
+    AGPT_ERR_DEVICE = -2,    /* HIP runtime error, no device */
+    AGPT_ERR_NOMEM = -3,
+    AGPT_ERR_LIMIT = -4      /* scene exceeds a kernel limit (e.g. BVH deeper than the traversal stack) */
+} agpt_status;
+
+typedef struct agpt_ctx agpt_ctx;
+typedef struct agpt_scene agpt_scene;
+
+/* material kinds: material.h:11-58 DisneyMaterial, material.h:60-81 MirrorMaterial; DIFFUSE_ONLY is a
+ * Material whose SetupBSDF adds a single DisneyDiffuse lobe (disney.h:25-38) -- BASELINE config 2's
+ * "Lambertian" (the reference has no Lambertian material). */
+enum { AGPT_MAT_DISNEY = 0, AGPT_MAT_MIRROR = 1, AGPT_MAT_DIFFUSE_ONLY = 2 };
+
+/* 32-byte BVH node, identical to the reference's BVHNode (bvhtrimesh.h:126-130) */
+typedef struct {
+    float bmin[3];
+    float bmax[3];
+    int32_t first; /* interior: index of the first child (pair first, first+1); leaf: first primitive */
+    int32_t count; /* 0 = interior */
+} agpt_bvh_node;
+
+/* Ray (camera.h:3-15); d need not be normalised, the library normalises it like Ray's ctor */
+typedef struct { float o[3]; float d[3]; float tmax; } agpt_ray;
+
+/* result of Scene::Intersect (scene.h:5-13) reduced to what identifies the hit */
+typedef struct {
+    int32_t hit;   /* 0/1 */
+    int32_t prim;  /* index into Scene::primitives (insertion order); -1 on miss / any-hit queries */
+    int32_t tri;   /* triangle meshes: index of the triangle's first index_type (= 3*triangle); else -1 */
+    float t, b1, b2;
+} agpt_hit;
+
+/* CameraDesc (camera.h:17-25) */
+typedef struct {
+    float lookfrom[3];
+    float lookat[3];
+    float vup[3];
+    float aspect_ratio;
+    float vfov;       /* degrees; reference default 45 */
+    float aperture;   /* reference default 0 */
+} agpt_camera_desc;
+
+typedef struct {
+    uint64_t closest_rays;    /* Scene::Intersect-equivalents: primary + continuation + MIS + emitter pass-through */
+    uint64_t anyhit_rays;     /* Scene::IntersectP-equivalents: shadow rays */
+    uint64_t interior_visits; /* interior nodes whose child pair was fetched (only if counters enabled) */
+    uint64_t tri_tests;       /* triangle tests (only if counters enabled) */
+    uint64_t shaded_vertices;
+    uint64_t samples;
+    uint64_t outliers;        /* NaN/inf samples zeroed (myapp.cpp:169-172) */
+    uint64_t iterations;      /* wavefront iterations executed */
+    double   trace_ms;        /* HIP-event time of the trace kernels over the call (stream the kernels ran on) */
+    double   total_ms;        /* HIP-event time of the whole call */
+    uint64_t trace_launches;
+} agpt_stats;
+
+/* parameters of one agpt_render call = MyApp::Tick's per-pixel loop (myapp.cpp:163-175) for a tile */
+typedef struct {
+    int32_t width, height;        /* film size W x H (Accumulator width/height, myapp.h:10) */
+    int32_t x0, y0, w, h;         /* tile to render, in film pixels */
+    int32_t spp_begin, spp_count; /* samples [spp_begin, spp_begin+spp_count) of every pixel */
+    uint32_t seed_base;           /* per-(pixel,sample) stream: WangHash((pixel + W*H*sample + 1)*17 + seed_base) */
+    int32_t max_depth;            /* PathTracer::MaxDepth (integrator.h:122), reference default 5 */
+    int32_t accum_pitch;          /* row pitch of accum in float4 pixels */
+    int32_t accum_row0;           /* film row (after the y flip) that accum's row 0 holds; tile rows map to
+                                     accum row (H-1-y) - accum_row0 */
+    int32_t samples_per_batch;    /* 0 = library default */
+    int32_t enable_counters;      /* 1 = also count interior visits / triangle tests (slower) */
+} agpt_render_params;
+
+const char* agpt_last_error(void);
+int agpt_version(void);
+
+/* context: picks the GPU.  stream = hipStream_t to launch on, or NULL for the null stream */
+int agpt_init(int device, agpt_ctx** out);
+int agpt_set_stream(agpt_ctx*, void* hip_stream);
+void agpt_destroy(agpt_ctx*);
+
+/* ---- scene building: mirrors the reference's scene-construction calls (myapp.cpp:13-114) ---------- */
+int agpt_scene_create(agpt_ctx*, agpt_scene** out);
+void agpt_scene_destroy(agpt_scene*);
+/* DisneyMaterial::Make / MirrorMaterial::Make (material.h:60-62,83-85): returns material id >= 0 */
+int agpt_scene_add_material(agpt_scene*, int type, const float color[3], float roughness, float metallic);
+/* scene->primitives.push_back(make_shared<BVHTriMesh>(TriangleMesh(indices, vertices, normals, texcoords), mat,
+ * maxPrimsInNode)) (bvhtrimesh.h:154-178): builds the binned-SAH BVH on the host.  indices are
+ * (vertex, normal, texcoord) triplets = index_type (trianglemesh.h:5-12); n_normals / n_texcoords may be 0.
+ * returns the primitive index (position in Scene::primitives) */
+int agpt_scene_add_mesh(agpt_scene*, const float* vertices, int n_vertices, const float* normals, int n_normals,
+                        const float* texcoords, int n_texcoords, const int32_t* indices, int n_indices,
+                        int material, int max_prims_in_node);
+/* scene->primitives.push_back(make_shared<Sphere>(center, r, material)); material -1 = nullptr */
+int agpt_scene_add_sphere(agpt_scene*, const float center[3], float radius, int material);
+/* Scene::addAreaLight(make_shared<Sphere>(center, r, nullptr), L) (scene.h:21-25): returns primitive index */
+int agpt_scene_add_area_light(agpt_scene*, const float center[3], float radius, const float L[3]);
+/* scene->lights.push_back(make_shared<UniformInfiniteLight>(L)) (lights.h:37-51): returns light index */
+int agpt_scene_add_uniform_infinite_light(agpt_scene*, const float L[3]);
+/* scene->camera = desc; Camera(desc) (camera.h:29-56,77-90) */
+int agpt_scene_set_camera(agpt_scene*, const agpt_camera_desc*);
+/* flatten + upload to HBM; must be called after the last add_* and before render/intersect */
+int agpt_scene_commit(agpt_scene*);
+
+/* BVH inspection (host copy, reference layout): nodes_out has agpt_mesh_num_nodes()+1 entries (slot 1 unused),
+ * prim_index_out the reordered Primitive::index list (bvhtrimesh.h:132-145,208) */
+int agpt_mesh_num_nodes(const agpt_scene*, int prim);
+int agpt_mesh_num_prims(const agpt_scene*, int prim);
+int agpt_mesh_get_bvh(const agpt_scene*, int prim, agpt_bvh_node* nodes_out, int32_t* prim_index_out);
+/* BVHTriMesh's constructor alone (bvhtrimesh.h:154-178,213-330), host-only -- needs no GPU and no context.
+ * indices as in agpt_scene_add_mesh.  nodes_out needs 2*(n_indices/3)+2 entries of capacity (total_nodes+1 are
+ * written, slot 1 unused); prim_index_out n_indices/3 entries.  Either output may be NULL. */
+int agpt_bvh_build(const float* vertices, int n_vertices, const int32_t* indices, int n_indices, int max_prims_in_node,
+                   agpt_bvh_node* nodes_out, int32_t* prim_index_out, int* total_nodes_out, int* max_depth_out);
+/* TriangleMesh::CreateBackdrop (trianglemesh.cpp:232-318), host-side scene prep.
+ * capacities: vertices/normals 3*2*(steps+5) floats, texcoords 2*2*(steps+5), indices 3*6*(steps+4) ints */
+int agpt_create_backdrop(const float origin[3], const float size[3], float radius, int steps, float* vertices,
+                         float* normals, float* texcoords, int32_t* indices, int* n_vertices, int* n_indices);
+
+/* ---- hot path -------------------------------------------------------------------------------------- */
+/* Scene::Intersect (any_hit=0, scene.h:5-13) / Scene::IntersectP (any_hit=1, scene.h:15-19) for n rays.
+ * rays/out are HOST arrays (copied in/out); BVHTriMesh::RecursiveHit/RecursiveHitP (bvhtrimesh.h:332-413),
+ * TriangleIntersect/P (trianglemesh.cpp:7-155), Sphere::Intersect/P (intersectable.h:164-226) run on the GPU. */
+int agpt_intersect_batch(agpt_scene*, const agpt_ray* rays, int n, agpt_hit* out, int any_hit, agpt_stats* stats);
+
+/* MyApp::Tick's loop body for every pixel of the tile and every sample in the range:
+ *   jitter -> Camera::GetRay -> PathTracer::Li -> NaN/inf reject -> Accumulator::AddSample  (myapp.cpp:165-173)
+ * accum_dev is a DEVICE pointer to float4 pixels (rgb + unused w); samples are ADDED in sample order, so
+ * successive calls continue a progressive render (Accumulator, myapp.h:17-32).  Returns after the work
+ * has been enqueued and, if stats != NULL, synchronised. */
+int agpt_render(agpt_scene*, const agpt_render_params*, float* accum_dev, agpt_stats* stats);
+
+/* Accumulator::CopyToSurface (myapp.h:34-41): lin2rgb(sum/samples) -> 0x00RRGGBB.  accum_dev DEVICE float4,
+ * out_rgb HOST uint32[w*h] */
+int agpt_resolve(agpt_ctx*, const float* accum_dev, int n_pixels, int samples, uint32_t* out_rgb);
+
+/* device memory helpers for hosts that do not bring their own allocator (tests, the C++ adapter) */
+int agpt_device_alloc(agpt_ctx*, size_t bytes, void** out_dev);
+int agpt_device_free(agpt_ctx*, void* dev);
+int agpt_device_memset(agpt_ctx*, void* dev, int value, size_t bytes);
+int agpt_device_download(agpt_ctx*, void* host_dst, const void* dev_src, size_t bytes);
+int agpt_device_upload(agpt_ctx*, void* dev_dst, const void* host_src, size_t bytes);
+
+/* known-answer entry points (each runs the device implementation of one hot-path function on one lane) */
+/* BSDF::f + BSDF::Pdf (reflection.h:114-123,174-188) on the canonical frame ng = ns = +z, ss = +x */
+int agpt_kat_bsdf_eval(agpt_scene*, int material, int n, const float* wo3, const float* wi3, float* f3_out, float* pdf_out);
+/* BSDF::Sample_f (reflection.h:124-172) */
+int agpt_kat_bsdf_sample(agpt_scene*, int material, int n, const float* wo3, const float* u2, float* wi3_out,
+                         float* f3_out, float* pdf_out, int32_t* specular_out);
+/* RNG stream of a (pixel, sample): first n floats (template.cpp:667-675 + cl/tools.cl:1-2) */
+int agpt_kat_rng(agpt_ctx*, uint32_t pixel, uint32_t wh, uint32_t sample, uint32_t seed_base, int n, float* out,
+                 uint32_t* seed_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

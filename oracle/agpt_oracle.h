@@ -116,6 +116,10 @@ void oracle_create_backdrop(const float origin[3], const float size[3], float ra
 void oracle_hex2lin(int hex, float out[3]);
 void oracle_rgb2lin(const float in[3], float out[3]);
 
+/* 0 = libm sinf/cosf/acosf (pinned against the reference outputs), 1 = correctly rounded through fp64 (what the HIP
+ * kernels compute); see oracle.c */
+void oracle_set_trig_mode(int mode);
+
 /* Pin helper: heightfield mesh of the survey's reference runs. */
 void oracle_pin_heightfield(int n, float S, float* verts, float* normals, float* uvs, int32_t* indices);
 

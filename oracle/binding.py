@@ -80,6 +80,7 @@ def lib():
     L.oracle_li.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), fp, C.POINTER(Stats)]
     L.oracle_create_backdrop.argtypes = [fp, fp, C.c_float, C.c_int, fp, fp, fp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.oracle_pin_heightfield.argtypes = [C.c_int, C.c_float, fp, fp, fp, ip]
+    L.oracle_set_trig_mode.argtypes = [C.c_int]
     L.oracle_hex2lin.argtypes = [C.c_int, fp]
     L.oracle_rgb2lin.argtypes = [fp, fp]
     _LIB = L
@@ -249,6 +250,13 @@ class OracleScene:
         st = Stats()
         self.L.oracle_li(self.h, r.ctypes.data_as(C.c_void_p), C.byref(state), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
         return out, state.value, st
+
+
+TRIG_LIBM, TRIG_CORRECTLY_ROUNDED = 0, 1
+
+
+def set_trig_mode(mode):
+    lib().oracle_set_trig_mode(int(mode))
 
 
 def wang_hash(s):

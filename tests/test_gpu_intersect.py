@@ -1,0 +1,91 @@
+"""GPU parity, closest-hit / any-hit queries: agpt_intersect_batch (Scene::Intersect / IntersectP on the GPU)
+against the CPU oracle on identical rays.  Bar: BIT-EXACT hit flag, primitive, triangle, t, b1, b2 -- the kernels do
+only IEEE +,-,*,/ in the reference's operation order (no FMA contraction; Markstein-corrected division)."""
+import numpy as np
+import pytest
+
+import ag_pathtracer_amd as ag
+from helpers import bits, gpu_scene, oracle_scene, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def check_closest(desc, rays):
+    g = gpu_scene(desc)
+    o = oracle_scene(desc)
+    gh, gst = g.Intersect(rays)
+    oh, ost = o.intersect(rays, any_hit=False)
+    assert np.array_equal(gh["hit"], oh["hit"])
+    assert np.array_equal(gh["prim"], oh["prim"])
+    assert np.array_equal(gh["tri"], oh["tri"])
+    m = oh["hit"] == 1
+    assert np.array_equal(bits(gh["t"][m]), bits(oh["t"][m]))
+    assert np.array_equal(bits(gh["b1"][m]), bits(oh["b1"][m]))
+    assert np.array_equal(bits(gh["b2"][m]), bits(oh["b2"][m]))
+    # the instrumented kernel walks exactly the nodes / triangles the reference's recursion does
+    assert gst.interior_visits == ost.interior_visits
+    assert gst.tri_tests == ost.tri_tests
+    gp, _ = g.IntersectP(rays)
+    op_, _ = o.intersect(rays, any_hit=True)
+    assert np.array_equal(gp["hit"], op_["hit"])
+    g.close()
+    return int(m.sum())
+
+
+def test_c1_backdrop_sphere():
+    desc = ag.scenes.scene_c1()
+    hits = check_closest(desc, random_rays(desc, 200000, seed=11))
+    assert hits > 20000
+
+
+def test_heightfield_70k():
+    desc = ag.scenes.scene_heightfield(187, disney=False)
+    hits = check_closest(desc, random_rays(desc, 300000, seed=12))
+    assert hits > 50000
+
+
+def test_c2_blob_multi_mesh_and_light_spheres():
+    desc = ag.scenes.scene_c2(n_seg=96)
+    hits = check_closest(desc, random_rays(desc, 300000, seed=13))
+    assert hits > 50000
+
+
+def test_c3_atrium_many_meshes():
+    desc = ag.scenes.scene_c3(scale=0.12)
+    hits = check_closest(desc, random_rays(desc, 200000, seed=14))
+    assert hits > 50000
+
+
+def test_edge_meshes():
+    """No normals / no uvs (default uvs (0,0),(1,0),(1,1)), a degenerate (zero-area) triangle that passes the
+    Moeller-Trumbore test only by rounding, duplicate triangles (identical centroids -> 2-prim leaves), a
+    single-triangle mesh (root is a leaf)."""
+    d = ag.SceneDesc("edge")
+    m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0.5, 0.5, 0], [2, 2, 2], [3, 3, 3], [2.5, 2.5, 2.5]], np.float32)
+    tris = np.array([[0, 1, 2], [1, 3, 2], [0, 1, 2], [5, 6, 7], [0, 4, 3]], np.int32)
+    idx = np.stack([tris.reshape(-1)] * 3, 1)
+    d.add_mesh(v, None, None, idx, m, 1)
+    d.add_mesh(v[:3] + np.float32([0, 0, -1]), None, None, np.stack([np.arange(3, dtype=np.int32)] * 3, 1), m, 1)
+    d.add_sphere([0.5, 0.5, 1.5], 0.4, m)
+    rays = random_rays(d, 100000, seed=15)
+    # rays along the degenerate triangle's line and through shared edges
+    extra = np.zeros(6, ag.RAY_DTYPE)
+    extra["o"] = [[1, 1, 1], [0.5, 0.5, 3], [0.25, 0.25, 3], [4, 4, 4], [0, 0, 3], [1, 0, 3]]
+    extra["d"] = [[1, 1, 1], [0, 0, -1], [0, 0, -1], [-1, -1, -1], [0, 0, -1], [0, 0, -1]]
+    extra["tmax"] = 3.402823466e+38
+    check_closest(d, np.concatenate([rays, extra]))
+
+
+def test_empty_and_invalid_inputs():
+    desc = ag.scenes.scene_c1()
+    g = gpu_scene(desc)
+    out, _ = g.Intersect(np.zeros(0, ag.RAY_DTYPE))
+    assert out.shape == (0,)
+    with pytest.raises(ag.AgptError):
+        bad = ag.Scene(g.ctx)
+        bad.add_mesh(np.zeros((3, 3), np.float32), None, None, np.zeros((0, 3), np.int32), -1)
+    uncommitted = ag.Scene(g.ctx)
+    with pytest.raises(ag.AgptError):
+        uncommitted.Intersect(np.zeros(4, ag.RAY_DTYPE))
+    g.close()

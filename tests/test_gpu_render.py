@@ -1,0 +1,85 @@
+"""GPU parity, full path: agpt_render (MyApp::Tick's per-pixel loop -> PathTracer::Li on the GPU) against the CPU
+oracle on identical per-(pixel, sample) RNG streams.
+
+Tolerance (fp32 radiance): the kernels evaluate the same IEEE expression tree as the oracle; the only
+implementation-defined ingredient is sin/cos/acos, which both sides define as the correctly rounded fp32 value
+(oracle trig mode 1; device: fp64 evaluation rounded once).  fp64 libm's differ by <1 ulp(fp64), so a rounded fp32
+result can differ in ~1e-8 of the calls.  Bar used below, per pixel of the accumulated image:
+    >= 99.9 % of pixels bit-identical, every pixel within rel 1e-4 (+abs 1e-6) except <= 1e-4 of the pixels
+    (a 1-ulp direction change that flips a hit/miss edge decides a whole path), image mean within rel 1e-4,
+and exactly equal ray counts (closest + any-hit) up to that same 1e-4 fraction.
+"""
+import numpy as np
+import pytest
+
+import ag_pathtracer_amd as ag
+from helpers import gpu_scene, oracle_scene
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(desc, W, H, spp, max_depth=5, tile=None, seed_base=0, spb=0):
+    g = gpu_scene(desc)
+    o = oracle_scene(desc, max_depth)
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        oacc, ost = o.render(W, H, spp, tile=tile, seed_base=seed_base, rng_mode=ob.RNG_PER_SAMPLE, threads=8)
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    gacc, gst = ag.PathTracer(max_depth).render_to_host(g, W, H, spp, tile=tile, seed_base=seed_base,
+                                                        samples_per_batch=spb, counters=True)
+    g.close()
+    a, b = gacc[..., :3].reshape(-1, 3), oacc[..., :3].reshape(-1, 3)
+    same = np.all(a.view(np.uint32) == b.view(np.uint32), axis=1)
+    close = np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-6, axis=1)
+    n = a.shape[0]
+    info = dict(bit_exact=float(same.mean()), close=float(close.mean()), n=n,
+                mean_rel=float(np.max(np.abs(a.mean(0, dtype=np.float64) - b.mean(0, dtype=np.float64)) /
+                                      np.maximum(b.mean(0, dtype=np.float64), 1e-12))),
+                rays=(gst.rays, ost.rays), closest=(gst.closest_rays, ost.closest_rays),
+                anyhit=(gst.anyhit_rays, ost.anyhit_rays), outliers=(gst.outliers, ost.outliers),
+                interior=(gst.interior_visits, ost.interior_visits), tris=(gst.tri_tests, ost.tri_tests))
+    print(desc.name, info)
+    assert info["bit_exact"] >= 0.999, info
+    assert info["close"] >= 1 - 1e-4, info
+    assert info["mean_rel"] <= 1e-4, info
+    assert abs(gst.rays - ost.rays) <= max(2, 1e-4 * ost.rays), info
+    assert gst.outliers == ost.outliers
+    return info
+
+
+def test_c1_256x256_1spp():
+    """BASELINE config 1 (Cornell-box-scale: backdrop + gold microfacet sphere + sphere light + sky)."""
+    compare(ag.scenes.scene_c1(), 256, 256, 1)
+
+
+def test_c1_multi_spp_batches_and_tile():
+    d = ag.scenes.scene_c1()
+    compare(d, 96, 64, 5, spb=2)                      # 3 batches (2+2+1): accumulation order across batches
+    compare(d, 128, 96, 2, tile=(32, 16, 64, 48))     # a tile of a larger film: global pixel seeds
+
+
+def test_c2_blob_diffuse_only():
+    """BASELINE config 2 geometry class at reduced size (single DisneyDiffuse lobe, three sphere lights + sky)."""
+    compare(ag.scenes.scene_c2(n_seg=64), 160, 90, 2)
+
+
+def test_c3_atrium_disney_nee_mis():
+    """BASELINE config 3 geometry class at reduced size (closed atrium, ~30 Disney materials incl. metals)."""
+    compare(ag.scenes.scene_c3(scale=0.05), 160, 90, 2)
+
+
+def test_heightfield_disney():
+    compare(ag.scenes.scene_heightfield(64, disney=True), 160, 90, 2)
+
+
+def test_lens_and_mirror_and_depth():
+    """Thin-lens camera (rejection-sampled disk: variable RNG draws), a perfectly specular mirror sphere
+    (specularBounce path, no NEE) and non-default MaxDepth."""
+    d = ag.scenes.scene_c1()
+    d.add_material(ag.MAT_MIRROR, [.9, .9, .9])
+    d.add_sphere([2.2, 0.0, 0.5], 1.0, 2)
+    d.set_camera([-1.46, 1.16, -4.64], [0, 0, 0], [0, 1, 0], 1.0, 45.0, 0.1)
+    compare(d, 96, 96, 2, max_depth=3)
+    compare(d, 64, 64, 1, max_depth=0)
