@@ -46,7 +46,8 @@ class Stats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("anyhit_rays", C.c_uint64), ("interior_visits", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("shaded_vertices", C.c_uint64), ("samples", C.c_uint64),
                 ("outliers", C.c_uint64), ("iterations", C.c_uint64), ("trace_ms", C.c_double),
-                ("total_ms", C.c_double), ("trace_launches", C.c_uint64)]
+                ("total_ms", C.c_double), ("trace_launches", C.c_uint64), ("root_tests", C.c_uint64),
+                ("ext_ms", C.c_double), ("mis_ms", C.c_double), ("shadow_ms", C.c_double)]
 
     @property
     def rays(self):
@@ -60,7 +61,8 @@ class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("x0", C.c_int32), ("y0", C.c_int32),
                 ("w", C.c_int32), ("h", C.c_int32), ("spp_begin", C.c_int32), ("spp_count", C.c_int32),
                 ("seed_base", C.c_uint32), ("max_depth", C.c_int32), ("accum_pitch", C.c_int32),
-                ("accum_row0", C.c_int32), ("samples_per_batch", C.c_int32), ("enable_counters", C.c_int32)]
+                ("accum_row0", C.c_int32), ("samples_per_batch", C.c_int32), ("enable_counters", C.c_int32),
+                ("enable_timing", C.c_int32)]
 
 
 def library_path():
@@ -342,12 +344,12 @@ class PathTracer:
         self.MaxDepth = int(maxDepth)
 
     def render(self, scene, W, H, spp, accum_ptr, tile=None, spp_begin=0, seed_base=0, accum_pitch=None, accum_row0=0,
-               samples_per_batch=0, counters=False, want_stats=True):
+               samples_per_batch=0, counters=False, timing=False, want_stats=True):
         """Adds `spp` samples per pixel of `tile` (x0, y0, w, h) into the DEVICE float4 buffer at accum_ptr."""
         x0, y0, w, h = tile if tile is not None else (0, 0, W, H)
         rp = RenderParams(W, H, x0, y0, w, h, spp_begin, spp, seed_base & 0xFFFFFFFF, self.MaxDepth,
                           accum_pitch if accum_pitch is not None else W, accum_row0, samples_per_batch,
-                          1 if counters else 0)
+                          1 if counters else 0, 1 if timing else 0)
         st = Stats()
         _check(scene.L.agpt_render(scene.h, C.byref(rp), C.c_void_p(int(accum_ptr)), C.byref(st) if want_stats else None),
                "agpt_render")

@@ -65,6 +65,10 @@ struct agpt_ctx {
     DevBuf<uint32_t> work;      // work-queue heads of the persistent trace launches
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
+    // per-launch HIP-event timing of the trace kernels (agpt_render_params::enable_timing)
+    std::vector<hipEvent_t> tev;
+    size_t tev_used = 0;
+    std::vector<int> tev_kind;  // 0 = closest (continuation), 1 = closest (MIS), 2 = any-hit
 };
 
 struct agpt_scene {
@@ -105,6 +109,27 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     else
         hipLaunchKernelGGL((k_trace<ANY, false>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
                            hits, occ, c->counters.p);
+}
+
+static hipEvent_t next_event(agpt_ctx* c) {
+    if (c->tev_used == c->tev.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        c->tev.push_back(e);
+    }
+    return c->tev[c->tev_used++];
+}
+
+template <bool ANY>
+static void launch_trace_timed(agpt_ctx* c, bool timing, int kind, const DevScene& sc, const uint32_t* queue,
+                               const uint32_t* count_ptr, uint32_t count_imm, uint32_t* work_head, const float4* ro,
+                               const float4* rd, DevHit* hits, uint32_t* occ, bool count) {
+    if (timing) {
+        (void)hipEventRecord(next_event(c), c->stream);
+        c->tev_kind.push_back(kind);
+    }
+    launch_trace<ANY>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, count);
+    if (timing) (void)hipEventRecord(next_event(c), c->stream);
 }
 
 extern "C" {
@@ -153,6 +178,7 @@ void agpt_destroy(agpt_ctx* c) {
     c->work.release();
     c->counters.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    for (auto& ev : c->tev) (void)hipEventDestroy(ev);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     delete c;
@@ -434,6 +460,7 @@ static void read_counters(const DevCounters& d, agpt_stats* st) {
     st->closest_rays = d.closest_rays;
     st->anyhit_rays = d.anyhit_rays;
     st->interior_visits = d.interior;
+    st->root_tests = d.roots;
     st->tri_tests = d.tris;
     st->shaded_vertices = d.shaded;
     st->outliers = d.outliers;
@@ -514,6 +541,9 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         q[i].counts = c->qcounts.p + 4 * i;
     }
     const bool count = rp->enable_counters != 0;
+    const bool timing = rp->enable_timing != 0 && stats != nullptr;
+    c->tev_used = 0;
+    c->tev_kind.clear();
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     uint64_t iterations = 0, launches = 0;
@@ -542,9 +572,9 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
             const int nxt = cur ^ 1;
             HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * sizeof(uint32_t), c->stream));
             HIP_TRY(hipMemsetAsync(c->work.p, 0, 3 * sizeof(uint32_t), c->stream));
-            launch_trace<false>(c, s->dev, q[cur].ext, &q[cur].counts[1], 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
-            launch_trace<false>(c, s->dev, q[cur].mis, &q[cur].counts[2], 0, c->work.p + 1, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
-            launch_trace<true>(c, s->dev, q[cur].shadow, &q[cur].counts[3], 0, c->work.p + 2, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+            launch_trace_timed<false>(c, timing, 0, s->dev, q[cur].ext, &q[cur].counts[1], 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
+            launch_trace_timed<false>(c, timing, 1, s->dev, q[cur].mis, &q[cur].counts[2], 0, c->work.p + 1, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
+            launch_trace_timed<true>(c, timing, 2, s->dev, q[cur].shadow, &q[cur].counts[3], 0, c->work.p + 2, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
             hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
             cur = nxt;
             iterations++;
@@ -567,6 +597,17 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         stats->total_ms = ms;
+        if (timing) {
+            for (size_t i = 0; i + 1 < c->tev_used; i += 2) {
+                float t = 0;
+                HIP_TRY(hipEventElapsedTime(&t, c->tev[i], c->tev[i + 1]));
+                int kind = c->tev_kind[i / 2];
+                stats->trace_ms += t;
+                if (kind == 0) stats->ext_ms += t;
+                else if (kind == 1) stats->mis_ms += t;
+                else stats->shadow_ms += t;
+            }
+        }
     }
     return AGPT_OK;
 }

@@ -53,7 +53,7 @@ struct RenderConsts {
 };
 
 struct DevCounters {
-    unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples;
+    unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples, roots;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -85,6 +85,7 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
     TraceCounters cnt;
     cnt.interior = 0;
     cnt.tris = 0;
+    cnt.roots = 0;
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(work_head, (uint32_t)AGPT_CHUNK);
@@ -105,6 +106,7 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
     if (COUNT) {
         atomicAdd(&counters->interior, (unsigned long long)cnt.interior);
         atomicAdd(&counters->tris, (unsigned long long)cnt.tris);
+        atomicAdd(&counters->roots, (unsigned long long)cnt.roots);
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (ANY)

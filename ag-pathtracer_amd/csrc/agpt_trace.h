@@ -123,6 +123,7 @@ __device__ __forceinline__ uint32_t encode_child(uint32_t node_index, uint32_t f
 struct TraceCounters {
     uint32_t interior;
     uint32_t tris;
+    uint32_t roots;
 };
 
 // Scene::Intersect (ANY=false) / Scene::IntersectP (ANY=true) for one ray on one lane.
@@ -152,6 +153,7 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
             continue;
         }
         if (P.n_tris == 0) continue;
+        if (COUNT) cnt.roots++;
         float dist;
         if (!box_test(P.root_bmin[0], P.root_bmin[1], P.root_bmin[2], P.root_bmax[0], P.root_bmax[1], P.root_bmax[2], r,
                       rayt, dist))

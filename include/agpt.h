@@ -79,6 +79,9 @@ typedef struct {
     double   trace_ms;        /* HIP-event time of the trace kernels over the call (stream the kernels ran on) */
     double   total_ms;        /* HIP-event time of the whole call */
     uint64_t trace_launches;
+    uint64_t root_tests;      /* mesh root-box tests, bvhtrimesh.h:187,195 (only if counters enabled) */
+    double   ext_ms, mis_ms, shadow_ms; /* trace_ms split: continuation / MIS closest-hit launches, any-hit launches
+                                           (only if agpt_render_params::enable_timing) */
 } agpt_stats;
 
 /* parameters of one agpt_render call = MyApp::Tick's per-pixel loop (myapp.cpp:163-175) for a tile */
@@ -93,6 +96,7 @@ typedef struct {
                                      accum row (H-1-y) - accum_row0 */
     int32_t samples_per_batch;    /* 0 = library default */
     int32_t enable_counters;      /* 1 = also count interior visits / triangle tests (slower) */
+    int32_t enable_timing;        /* 1 = bracket every trace launch with HIP events on the launch stream */
 } agpt_render_params;
 
 const char* agpt_last_error(void);
