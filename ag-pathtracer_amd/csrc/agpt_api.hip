@@ -343,6 +343,9 @@ int agpt_scene_commit(agpt_scene* s) {
     s->dev.n_lights = (int)lights.size();
     s->dev.n_materials = (int)s->materials.size();
     s->dev.n_infinite = n_inf;
+    s->dev.n_meshes = 0;
+    for (const DevPrim& dp : flat.prims)
+        if (dp.type == AGPT_PRIM_MESH && dp.n_tris > 0) s->dev.n_meshes++;
     s->dev.cam = s->cam;
     s->committed = true;
     return AGPT_OK;

@@ -291,10 +291,12 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
     out.tri_verts.resize(3 * tri_base);
     out.tri_shade.resize(4 * tri_base);
 
+    int mesh_ordinal = 0;
     for (size_t pi = 0; pi < prims.size(); pi++) {
         const HostPrim& hp = prims[pi];
         DevPrim dp;
         std::memset(&dp, 0, sizeof(dp));
+        dp.mesh_ordinal = mesh_ordinal;
         dp.type = hp.type;
         dp.material = hp.material;
         dp.arealight = hp.arealight;
@@ -314,6 +316,7 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
         dp.root = (int32_t)nb;
         dp.tri_base = (int32_t)tb;
         dp.n_tris = n_tris;
+        if (n_tris > 0) mesh_ordinal++;
         dp.has_normals = mesh.normals.empty() ? 0 : 1;
         out.max_depth = std::max(out.max_depth, mesh.max_depth);
         // nodes: rebase `first` to global node / slot indices

@@ -86,6 +86,7 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
     cnt.interior = 0;
     cnt.tris = 0;
     cnt.roots = 0;
+    cnt.last_mesh = 0;
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(work_head, (uint32_t)AGPT_CHUNK);

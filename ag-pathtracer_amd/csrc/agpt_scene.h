@@ -40,7 +40,7 @@ struct DevPrim {
     int32_t tri_base;   // mesh: global id of its first triangle
     int32_t has_normals;
     int32_t n_tris;
-    int32_t pad0;
+    int32_t mesh_ordinal;  // number of non-empty meshes before this primitive in Scene::primitives
     float cx, cy, cz, r;  // sphere (intersectable.h:161-162)
     float r2;
     float root_bmin[3];   // mesh root bounds (bvhtrimesh.h:185-198 tests them before descending)
@@ -79,6 +79,7 @@ struct DevScene {
     const DevLight* lights;
     int32_t n_prims, n_lights, n_materials;
     int32_t n_infinite;        // number of IsInfinite() lights
+    int32_t n_meshes;          // non-empty mesh primitives
     DevCamera cam;
 };
 

@@ -124,10 +124,22 @@ struct TraceCounters {
     uint32_t interior;
     uint32_t tris;
     uint32_t roots;
+    uint32_t last_mesh;
 };
 
 // Scene::Intersect (ANY=false) / Scene::IntersectP (ANY=true) for one ray on one lane.
 // stack: this lane's LDS column, element k at stack[k * stride].
+//
+// The reference walks Scene::primitives in order and finishes each BVHTriMesh before touching the next one
+// (scene.h:5-19).  A wave doing that in lockstep idles at every mesh boundary, so the walk is split in two:
+//   phase A (wave-uniform, primitive records come through scalar loads): test every primitive's root box /
+//           sphere against the ray's INITIAL t and keep a per-lane bit mask of the ones that can be hit at all --
+//           the slab test and the sphere test are monotone in ray.t, so a primitive missed at the initial t is
+//           missed at any later (smaller) t and the reference would skip it too;
+//   phase B (per lane): visit the surviving primitives in list order, RE-TESTING the root box at the current t
+//           exactly where the reference tests it (bvhtrimesh.h:187,195), then traverse.  Lanes move on to their
+//           next primitive independently.
+// Decisions, visit order, accepted hits and the work counters are those of the reference's recursion.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, float tmax_in, DevHit& hit,
                                             uint32_t* stack, int stride, TraceCounters& cnt) {
@@ -138,30 +150,58 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
     hit.b1 = 0.f;
     hit.b2 = 0.f;
 
-    for (int pi = 0; pi < sc.n_prims; ++pi) {
-        const DevPrim& P = sc.prims[pi];
-        if (P.type == AGPT_PRIM_SPHERE) {
-            float root;
-            if (sphere_test(P, r, rayt, root)) {
-                if (ANY) return true;
-                rayt = root;
-                hit.t = root;
-                hit.id = AGPT_HIT_SPHERE | (uint32_t)pi;
-                hit.b1 = 0.f;
-                hit.b2 = 0.f;
+    for (int base = 0; base < sc.n_prims; base += 64) {
+        const int nchunk = min(64, sc.n_prims - base);
+        // ---- phase A ------------------------------------------------------------------------------------
+        unsigned long long mask = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            const DevPrim& P = sc.prims[base + k];
+            bool h;
+            if (P.type == AGPT_PRIM_SPHERE) {
+                float root;
+                h = sphere_test(P, r, rayt, root);
+            } else {
+                float dist;
+                h = P.n_tris > 0 && box_test(P.root_bmin[0], P.root_bmin[1], P.root_bmin[2], P.root_bmax[0], P.root_bmax[1],
+                                             P.root_bmax[2], r, rayt, dist);
             }
-            continue;
+            mask |= (unsigned long long)(h ? 1u : 0u) << k;
         }
-        if (P.n_tris == 0) continue;
-        if (COUNT) cnt.roots++;
-        float dist;
-        if (!box_test(P.root_bmin[0], P.root_bmin[1], P.root_bmin[2], P.root_bmax[0], P.root_bmax[1], P.root_bmax[2], r,
-                      rayt, dist))
-            continue;
-
-        uint32_t cur = P.root_enc;
+        // ---- phase B ------------------------------------------------------------------------------------
+        uint32_t cur = 0;
+        bool in_mesh = false;
         int sp = 0;
         for (;;) {
+            if (!in_mesh) {
+                if (mask == 0) break;
+                const int k = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int pi = base + k;
+                const DevPrim& P = sc.prims[pi];
+                if (P.type == AGPT_PRIM_SPHERE) {
+                    float root;
+                    if (sphere_test(P, r, rayt, root)) {
+                        if (ANY) {
+                            if (COUNT) cnt.roots += (uint32_t)P.mesh_ordinal;
+                            return true;
+                        }
+                        rayt = root;
+                        hit.t = root;
+                        hit.id = AGPT_HIT_SPHERE | (uint32_t)pi;
+                        hit.b1 = 0.f;
+                        hit.b2 = 0.f;
+                    }
+                    continue;
+                }
+                float dist;
+                if (!box_test(P.root_bmin[0], P.root_bmin[1], P.root_bmin[2], P.root_bmax[0], P.root_bmax[1], P.root_bmax[2],
+                              r, rayt, dist))
+                    continue;
+                cur = P.root_enc;
+                sp = 0;
+                in_mesh = true;
+                if (ANY && COUNT) cnt.last_mesh = (uint32_t)P.mesh_ordinal + 1u;
+            }
             if (!(cur & AGPT_ENC_LEAF)) {
                 // interior: fetch the child pair (one 64-B line)
                 const float4* np = sc.nodes + 2 * (size_t)cur;
@@ -204,7 +244,10 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
                     if (COUNT) cnt.tris++;
                     float t, b1, b2;
                     if (tri_test(V3(q0.x, q0.y, q0.z), V3(q1.x, q1.y, q1.z), V3(q2.x, q2.y, q2.z), r, rayt, t, b1, b2)) {
-                        if (ANY) return true;
+                        if (ANY) {
+                            if (COUNT) cnt.roots += cnt.last_mesh;
+                            return true;
+                        }
                         // quirk 11: a degenerate triangle is rejected after the t test without touching hit / ray.t
                         if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
                             rayt = t;
@@ -216,10 +259,15 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
                     }
                 }
             }
-            if (sp == 0) break;
+            if (sp == 0) {
+                in_mesh = false;
+                continue;
+            }
             sp--;
             cur = stack[sp * stride];
         }
     }
+    // the reference root-tests every non-empty mesh of the list on a full walk (bvhtrimesh.h:187,195)
+    if (COUNT) cnt.roots += (uint32_t)sc.n_meshes;
     return hit.id != AGPT_HIT_MISS;
 }

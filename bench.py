@@ -37,35 +37,57 @@ def algorithmic_bytes(closest, anyhit, roots, interior, tris):
     return 28 * (closest + anyhit) + 16 * closest + 4 * anyhit + 32 * roots + 64 * interior + 88 * tris
 
 
-def cpu_baseline(desc, W, H, max_depth):
-    """Times the CPU oracle (kind 'port': the C restatement of the reference's path, pinned to the reference's
-    recorded outputs -- the reference itself cannot travel to this box) on centred tiles of the same film."""
-    from oracle import binding as ob
-    ob.build()
-    cores = os.cpu_count() or 1
+def effective_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:  # noqa: BLE001
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / float(per) + 0.5)))
+        except Exception:  # noqa: BLE001
+            pass
+    return n
+
+
+def cpu_baseline(desc, W, H, max_depth, budget_s=12.0):
+    """Times the CPU oracle (kind 'port': the C restatement of the reference's path, pinned to the reference's
+    recorded outputs -- the reference itself cannot travel to this box) on centred tiles of the same film,
+    about `budget_s` seconds single-threaded (the reference as shipped: myapp.cpp:163-175) and the same again with
+    OpenMP over scanlines on all usable host cores."""
+    from oracle import binding as ob
+    ob.build()
+    cores = effective_cores()
     o = desc.instantiate(ob.OracleScene())
     o.set_max_depth(max_depth)
-    # single thread (the reference as shipped is single-threaded: myapp.cpp:163-175)
-    tw, th = 320, 180
-    tile = ((W - tw) // 2, (H - th) // 2, tw, th)
-    t0 = time.time()
-    _, st1 = o.render(W, H, 1, tile=tile, seed_base=0, rng_mode=ob.RNG_PER_SAMPLE, threads=1)
-    dt1 = time.time() - t0
-    # all host cores, OpenMP over scanlines
-    tw, th = 960, 540
-    tile = ((W - tw) // 2, (H - th) // 2, tw, th)
-    spp = 1
-    t0 = time.time()
-    _, stn = o.render(W, H, spp, tile=tile, seed_base=0, rng_mode=ob.RNG_PER_SAMPLE, threads=cores)
-    dtn = time.time() - t0
+
+    def timed(tw, th, threads):
+        tile = ((W - tw) // 2, (H - th) // 2, tw, th)
+        t0 = time.time()
+        _, st = o.render(W, H, 1, tile=tile, seed_base=0, rng_mode=ob.RNG_PER_SAMPLE, threads=threads)
+        probe = max(time.time() - t0, 1e-3)
+        spp = int(max(1, min(64, budget_s / probe)))
+        t0 = time.time()
+        _, st = o.render(W, H, spp, tile=tile, seed_base=0, rng_mode=ob.RNG_PER_SAMPLE, threads=threads)
+        return st, time.time() - t0, spp
+
+    st1, dt1, spp1 = timed(320, 180, 1)
+    stn, dtn, sppn = timed(960, 540, cores)
     return {
         "value": round(stn.rays / dtn / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": "centred %dx%d tile of the 1920x1080 film at %d spp (%d rays, %.1f s) on %d threads; "
-                  "single thread: centred 320x180 tile at 1 spp (%d rays, %.1f s)" % (tw, th, spp, stn.rays, dtn, cores, st1.rays, dt1),
+        "sample": "centred 960x540 tile of the 1920x1080 film at %d spp (%d rays, %.1f s) on %d threads; "
+                  "single thread: centred 320x180 tile at %d spp (%d rays, %.1f s)"
+                  % (sppn, stn.rays, dtn, cores, spp1, st1.rays, dt1),
         "single_thread_value": round(st1.rays / dt1 / 1e6, 3),
         "rays_per_sample": round(stn.rays / float(stn.samples), 2),
     }
