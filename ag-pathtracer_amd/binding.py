@@ -294,22 +294,24 @@ class Scene:
                                         order.ctypes.data_as(C.POINTER(C.c_int32))), "agpt_mesh_get_bvh")
         return nodes, order
 
-    def _intersect(self, rays, any_hit):
+    def _intersect(self, rays, any_hit, counters):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         out = np.zeros(rays.shape[0], HIT_DTYPE)
         st = Stats()
         _check(self.L.agpt_intersect_batch(self.h, rays.ctypes.data_as(C.c_void_p), rays.shape[0],
-                                           out.ctypes.data_as(C.c_void_p), int(any_hit), C.byref(st)),
+                                           out.ctypes.data_as(C.c_void_p), int(any_hit),
+                                           C.byref(st) if counters else None),
                "agpt_intersect_batch")
         return out, st
 
-    def Intersect(self, rays):
-        """Scene::Intersect for a batch of rays (scene.h:5-13)."""
-        return self._intersect(rays, 0)
+    def Intersect(self, rays, counters=False):
+        """Scene::Intersect for a batch of rays (scene.h:5-13).  counters=True runs the instrumented kernel
+        (work counters in the returned stats); the default runs the production kernel."""
+        return self._intersect(rays, 0, counters)
 
-    def IntersectP(self, rays):
+    def IntersectP(self, rays, counters=False):
         """Scene::IntersectP for a batch of rays (scene.h:15-19)."""
-        return self._intersect(rays, 1)
+        return self._intersect(rays, 1, counters)
 
     def bsdf_eval(self, material, wo, wi):
         wo, pwo = _f(np.asarray(wo).reshape(-1, 3))

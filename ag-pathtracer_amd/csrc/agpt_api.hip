@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -65,6 +66,7 @@ struct agpt_ctx {
     DevBuf<uint32_t> work;      // work-queue heads of the persistent trace launches
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
+    bool force_generic = false;  // AGPT_FORCE_GENERIC=1: always use the generic k_trace (tests)
     // per-launch HIP-event timing of the trace kernels (agpt_render_params::enable_timing)
     std::vector<hipEvent_t> tev;
     size_t tev_used = 0;
@@ -103,7 +105,10 @@ template <bool ANY>
 static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
                          uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, bool count) {
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
-    if (count)
+    if (!count && sc.n_prims <= 64 && !c->force_generic)
+        hipLaunchKernelGGL((k_trace_fast<ANY>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
+                           hits, occ, c->counters.p);
+    else if (count)
         hipLaunchKernelGGL((k_trace<ANY, true>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
                            hits, occ, c->counters.p);
     else
@@ -152,6 +157,8 @@ int agpt_init(int device, agpt_ctx** out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(uint32_t)));
+    const char* fg = getenv("AGPT_FORCE_GENERIC");
+    c->force_generic = fg && fg[0] == '1';
     *out = c.release();
     return AGPT_OK;
 }

@@ -117,6 +117,217 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Production trace kernel (scenes with <= 64 primitives; the generic k_trace above stays as the instrumented /
+// fallback variant and both are checked against the oracle).  Same decisions as trace_scene(), restructured for
+// wave efficiency on 64-wide CDNA4 wavefronts:
+//   * persistent waves with IN-FLIGHT REFILL: when at least AGPT_REFILL lanes have retired their rays the wave
+//     pulls that many new rays off the queue (one atomic per refill) instead of idling until all 64 are done;
+//   * while-while traversal: every lane first descends interior nodes (the hot, convergent body), leaves are
+//     processed once all lanes have reached one, then lanes whose mesh is finished pick their next primitive;
+//   * the wave-uniform phase-A filter uses the cheap slab test (b-O)*RN(1/D) with a widened reject margin, which
+//     can only over-accept; the exact Bounds::Intersect is re-run per lane where the reference runs it.
+#define AGPT_REFILL 20
+
+template <bool ANY>
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+             uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+             DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters) {
+    __shared__ uint32_t s_stack[AGPT_STACK_DEPTH * AGPT_BLOCK];
+    uint32_t* stack = s_stack + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t count = count_ptr ? *count_ptr : count_imm;
+    const int n_prims = sc.n_prims;
+    const unsigned long long all_prims = n_prims >= 64 ? ~0ull : ((1ull << n_prims) - 1ull);
+
+    bool active = false, in_mesh = false;
+    bool exhausted = false;  // wave-uniform
+    uint32_t pid = 0, cur = 0, hid = AGPT_HIT_MISS;
+    int sp = 0;
+    float rayt = 0.f, hb1 = 0.f, hb2 = 0.f;
+    unsigned long long mask = 0;
+    TraceRay r;
+    r.O = V3s(0.f);
+    r.D = V3(0.f, 0.f, 1.f);
+    r.R = V3s(1.f);
+    r.fast = true;
+
+    for (;;) {
+        // ---- refill ---------------------------------------------------------------------------------------
+        unsigned long long act = __ballot(active);
+        int n_active = __popcll(act);
+        if (!exhausted && n_active <= 64 - AGPT_REFILL) {
+            const int n_idle = 64 - n_active;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(work_head, (uint32_t)n_idle);
+            base = __shfl(base, 0);
+            if (base + (uint32_t)n_idle >= count) exhausted = true;
+            bool fresh = false;
+            if (!active) {
+                uint32_t i = base + (uint32_t)__popcll(~act & lt_mask);
+                if (i < count) {
+                    pid = queue ? queue[i] : i;
+                    float4 o = ray_o[pid], d = ray_d[pid];
+                    r = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
+                    rayt = o.w;
+                    hid = AGPT_HIT_MISS;
+                    hb1 = 0.f;
+                    hb2 = 0.f;
+                    in_mesh = false;
+                    sp = 0;
+                    fresh = true;
+                    active = true;
+                }
+            }
+            if (__ballot(fresh)) {
+                // phase A: conservative per-primitive filter at the initial t (wave-uniform loop)
+                unsigned long long m = 0;
+                for (int k = 0; k < n_prims; ++k) {
+                    const DevPrim& P = sc.prims[k];
+                    bool h;
+                    if (P.type == AGPT_PRIM_SPHERE) {
+                        float root;
+                        h = sphere_test(P, r, rayt, root);
+                    } else {
+                        float t0x = (P.root_bmin[0] - r.O.x) * r.R.x, t1x = (P.root_bmax[0] - r.O.x) * r.R.x;
+                        float t0y = (P.root_bmin[1] - r.O.y) * r.R.y, t1y = (P.root_bmax[1] - r.O.y) * r.R.y;
+                        float t0z = (P.root_bmin[2] - r.O.z) * r.R.z, t1z = (P.root_bmax[2] - r.O.z) * r.R.z;
+                        float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
+                        float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), rayt));
+                        // exact test rejects iff tmax*1.00000024 < tmin; products are within 2 ulp of the quotients
+                        h = P.n_tris > 0 && !(tmax * 1.000002f < tmin);
+                    }
+                    m |= (unsigned long long)(h ? 1u : 0u) << k;
+                }
+                if (fresh) mask = r.fast ? m : all_prims;
+            }
+            act = __ballot(active);
+        }
+        if (act == 0) break;
+
+        // ---- traversal round --------------------------------------------------------------------------------
+        for (;;) {
+            // A: lanes between meshes pick their next primitive (list order) or retire
+            while (active && !in_mesh) {
+                if (mask == 0) {
+                    if (ANY)
+                        occluded[pid] = 0u;
+                    else {
+                        DevHit h;
+                        h.t = rayt;
+                        h.id = hid;
+                        h.b1 = hb1;
+                        h.b2 = hb2;
+                        hits[pid] = h;
+                    }
+                    active = false;
+                    break;
+                }
+                const int k = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const DevPrim& P = sc.prims[k];
+                if (P.type == AGPT_PRIM_SPHERE) {
+                    float root;
+                    if (sphere_test(P, r, rayt, root)) {
+                        if (ANY) {
+                            occluded[pid] = 1u;
+                            active = false;
+                            break;
+                        }
+                        rayt = root;
+                        hid = AGPT_HIT_SPHERE | (uint32_t)k;
+                        hb1 = 0.f;
+                        hb2 = 0.f;
+                    }
+                    continue;
+                }
+                float dist;
+                if (!box_test(P.root_bmin[0], P.root_bmin[1], P.root_bmin[2], P.root_bmax[0], P.root_bmax[1], P.root_bmax[2],
+                              r, rayt, dist))
+                    continue;
+                cur = P.root_enc;
+                sp = 0;
+                in_mesh = true;
+            }
+            // B: descend interior nodes until a leaf (or the mesh is exhausted)
+            while (active && in_mesh && !(cur & AGPT_ENC_LEAF)) {
+                const float4* np = sc.nodes + 2 * (size_t)cur;
+                float4 a0 = np[0], a1 = np[1], b0 = np[2], b1 = np[3];
+                float dl, dr;
+                bool hl = box_test(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
+                bool hr = box_test(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
+                uint32_t encl = encode_child(cur, __float_as_uint(a1.z), __float_as_uint(a1.w));
+                uint32_t encr = encode_child(cur + 1, __float_as_uint(b1.z), __float_as_uint(b1.w));
+                if (hl && hr) {
+                    bool swap = ANY ? false : (dr < dl);
+                    stack[sp * AGPT_BLOCK] = swap ? encl : encr;
+                    sp++;
+                    cur = swap ? encr : encl;
+                } else if (hl) {
+                    cur = encl;
+                } else if (hr) {
+                    cur = encr;
+                } else if (sp == 0) {
+                    in_mesh = false;
+                } else {
+                    sp--;
+                    cur = stack[sp * AGPT_BLOCK];
+                }
+            }
+            // C: leaf
+            if (active && in_mesh) {
+                uint32_t first, cnt;
+                if ((cur & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
+                    float4 n1 = sc.nodes[2 * (size_t)(cur & 0x0FFFFFFFu) + 1];
+                    first = __float_as_uint(n1.z);
+                    cnt = __float_as_uint(n1.w);
+                } else {
+                    first = cur & 0x0FFFFFFFu;
+                    cnt = ((cur >> 28) & 7u) + 1u;
+                }
+                bool done = false;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
+                    float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    float t, b1, b2;
+                    if (tri_test(V3(q0.x, q0.y, q0.z), V3(q1.x, q1.y, q1.z), V3(q2.x, q2.y, q2.z), r, rayt, t, b1, b2)) {
+                        if (ANY) {
+                            done = true;
+                            break;
+                        }
+                        if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
+                            rayt = t;
+                            hid = __float_as_uint(q0.w);
+                            hb1 = b1;
+                            hb2 = b2;
+                        }
+                    }
+                }
+                if (ANY && done) {
+                    occluded[pid] = 1u;
+                    active = false;
+                } else if (sp == 0) {
+                    in_mesh = false;
+                } else {
+                    sp--;
+                    cur = stack[sp * AGPT_BLOCK];
+                }
+            }
+            act = __ballot(active);
+            if (act == 0) break;
+            if (!exhausted && __popcll(act) <= 64 - AGPT_REFILL) break;
+        }
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (ANY)
+            atomicAdd(&counters->anyhit_rays, (unsigned long long)count);
+        else
+            atomicAdd(&counters->closest_rays, (unsigned long long)count);
+    }
+}
+
 // agpt_intersect_batch: Ray ctor (camera.h:6) normalises D
 __global__ void k_prepare_rays(const agpt_ray* __restrict__ in, int n, float4* __restrict__ ray_o, float4* __restrict__ ray_d) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 def check_closest(desc, rays):
     g = gpu_scene(desc)
     o = oracle_scene(desc)
-    gh, gst = g.Intersect(rays)
+    gh, gst = g.Intersect(rays, counters=True)   # instrumented generic kernel
+    gf, _ = g.Intersect(rays)                     # production kernel
+    assert gh.tobytes() == gf.tobytes()
     oh, ost = o.intersect(rays, any_hit=False)
     assert np.array_equal(gh["hit"], oh["hit"])
     assert np.array_equal(gh["prim"], oh["prim"])
@@ -26,8 +28,10 @@ def check_closest(desc, rays):
     assert gst.interior_visits == ost.interior_visits
     assert gst.tri_tests == ost.tri_tests
     gp, _ = g.IntersectP(rays)
+    gpc, _ = g.IntersectP(rays, counters=True)
     op_, _ = o.intersect(rays, any_hit=True)
     assert np.array_equal(gp["hit"], op_["hit"])
+    assert np.array_equal(gpc["hit"], op_["hit"])
     g.close()
     return int(m.sum())
 
@@ -89,3 +93,35 @@ def test_empty_and_invalid_inputs():
     with pytest.raises(ag.AgptError):
         uncommitted.Intersect(np.zeros(4, ag.RAY_DTYPE))
     g.close()
+
+
+def test_more_than_64_primitives_uses_generic_kernel():
+    """> 64 primitives: the 64-bit primitive mask of the production kernel does not apply and the generic kernel runs
+    (chunks of 64 in list order)."""
+    rng = np.random.RandomState(5)
+    d = ag.SceneDesc("many")
+    m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
+    for i in range(70):
+        c = rng.uniform(-4, 4, 3)
+        v, n, t, idx = ag.scenes.blob_mesh(8, 7, center=tuple(c), radius=0.5, seed=i)
+        d.add_mesh(v, n if i % 2 else None, t if i % 3 else None, idx, m, 1)
+    for i in range(5):
+        d.add_sphere(rng.uniform(-4, 4, 3), 0.4, m)
+    hits = check_closest(d, random_rays(d, 150000, seed=16))
+    assert hits > 20000
+
+
+def test_generic_kernel_forced(monkeypatch):
+    """The generic (reference-order, instrumentable) kernel and the production kernel give identical records."""
+    desc = ag.scenes.scene_c3(scale=0.05)
+    rays = random_rays(desc, 100000, seed=17)
+    g = gpu_scene(desc)
+    fast, _ = g.Intersect(rays)       # production kernel
+    g.close()
+    monkeypatch.setenv("AGPT_FORCE_GENERIC", "1")
+    ctx = ag.Context(0)
+    s = desc.instantiate(ag.Scene(ctx))
+    gen, _ = s.Intersect(rays)
+    s.close()
+    ctx.close()
+    assert fast.tobytes() == gen.tobytes()

@@ -28,8 +28,12 @@ def compare(desc, W, H, spp, max_depth=5, tile=None, seed_base=0, spb=0):
     finally:
         ob.set_trig_mode(ob.TRIG_LIBM)
     gacc, gst = ag.PathTracer(max_depth).render_to_host(g, W, H, spp, tile=tile, seed_base=seed_base,
-                                                        samples_per_batch=spb, counters=True)
+                                                        samples_per_batch=spb, counters=True)   # instrumented kernels
+    gfast, gfst = ag.PathTracer(max_depth).render_to_host(g, W, H, spp, tile=tile, seed_base=seed_base,
+                                                          samples_per_batch=spb)                # production kernels
     g.close()
+    assert gfast.tobytes() == gacc.tobytes()
+    assert gfst.rays == gst.rays
     a, b = gacc[..., :3].reshape(-1, 3), oacc[..., :3].reshape(-1, 3)
     same = np.all(a.view(np.uint32) == b.view(np.uint32), axis=1)
     close = np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-6, axis=1)
