@@ -1,6 +1,7 @@
 // agpt_api.hip -- the C ABI of include/agpt.h on top of the kernels in agpt_kernels.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -66,6 +67,8 @@ struct agpt_ctx {
     DevBuf<uint32_t> work;      // work-queue heads of the persistent trace launches
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
+    int blocks_per_cu = 4;       // AGPT_BLOCKS_PER_CU
+    int refill = AGPT_REFILL;    // AGPT_REFILL: idle lanes that trigger an in-flight refill
     bool force_generic = false;  // AGPT_FORCE_GENERIC=1: always use the generic k_trace (tests)
     // per-launch HIP-event timing of the trace kernels (agpt_render_params::enable_timing)
     std::vector<hipEvent_t> tev;
@@ -99,7 +102,7 @@ static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
     return AGPT_OK;
 }
 
-static int trace_grid(const agpt_ctx* c) { return c->num_cus * 4; }
+static int trace_grid(const agpt_ctx* c) { return c->num_cus * c->blocks_per_cu; }
 
 template <bool ANY>
 static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
@@ -107,7 +110,7 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
     if (!count && sc.n_prims <= 64 && !c->force_generic)
         hipLaunchKernelGGL((k_trace_fast<ANY>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
-                           hits, occ, c->counters.p);
+                           hits, occ, c->counters.p, c->refill);
     else if (count)
         hipLaunchKernelGGL((k_trace<ANY, true>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
                            hits, occ, c->counters.p);
@@ -159,6 +162,8 @@ int agpt_init(int device, agpt_ctx** out) {
     HIP_TRY(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(uint32_t)));
     const char* fg = getenv("AGPT_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    if (const char* bp = getenv("AGPT_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(bp));
+    if (const char* rf = getenv("AGPT_REFILL")) c->refill = std::min(64, std::max(1, atoi(rf)));
     *out = c.release();
     return AGPT_OK;
 }
@@ -459,7 +464,7 @@ static int ensure_pool(agpt_ctx* c, size_t paths) {
     for (int i = 0; i < 2; i++)
         for (int j = 0; j < 4; j++)
             if ((rc = c->q[i][j].ensure(paths))) return rc;
-    if ((rc = c->qcounts.ensure(8))) return rc;
+    if ((rc = c->qcounts.ensure(8 * AGPT_QSTRIDE))) return rc;
     if ((rc = c->work.ensure(4096))) return rc;
     if ((rc = c->counters.ensure(1))) return rc;
     c->pool_paths = paths;
@@ -548,7 +553,7 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     Queues q[2];
     for (int i = 0; i < 2; i++) {
         q[i].active = c->q[i][0].p; q[i].ext = c->q[i][1].p; q[i].mis = c->q[i][2].p; q[i].shadow = c->q[i][3].p;
-        q[i].counts = c->qcounts.p + 4 * i;
+        q[i].counts = c->qcounts.p + 4 * AGPT_QSTRIDE * i;
     }
     const bool count = rp->enable_counters != 0;
     const bool timing = rp->enable_timing != 0 && stats != nullptr;
@@ -580,11 +585,11 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
                 if (it > 4096) return fail(AGPT_ERR_LIMIT, "agpt_render: path did not terminate");
             }
             const int nxt = cur ^ 1;
-            HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * sizeof(uint32_t), c->stream));
-            HIP_TRY(hipMemsetAsync(c->work.p, 0, 3 * sizeof(uint32_t), c->stream));
-            launch_trace_timed<false>(c, timing, 0, s->dev, q[cur].ext, &q[cur].counts[1], 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
-            launch_trace_timed<false>(c, timing, 1, s->dev, q[cur].mis, &q[cur].counts[2], 0, c->work.p + 1, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
-            launch_trace_timed<true>(c, timing, 2, s->dev, q[cur].shadow, &q[cur].counts[3], 0, c->work.p + 2, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+            HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
+            HIP_TRY(hipMemsetAsync(c->work.p, 0, 96 * sizeof(uint32_t), c->stream));
+            launch_trace_timed<false>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
+            launch_trace_timed<false>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + 32, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
+            launch_trace_timed<true>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 64, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
             hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
             cur = nxt;
             iterations++;

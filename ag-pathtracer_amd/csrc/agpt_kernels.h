@@ -38,10 +38,12 @@ struct PathBuffers {
     float4 *c1, *c2;              // pending NEE contributions (light leg / BSDF leg)
 };
 
+#define AGPT_QSTRIDE 32  // queue counters live on separate 128-B lines: same-line atomics serialise (~11 ns each)
 struct Queues {
     uint32_t *active, *ext, *mis, *shadow;   // path ids
-    uint32_t* counts;                        // [0]=active [1]=ext [2]=mis [3]=shadow
+    uint32_t* counts;                        // [q * AGPT_QSTRIDE]: q = 0 active, 1 ext, 2 mis, 3 shadow
 };
+#define QCOUNT(q, i) ((q).counts[(i) * AGPT_QSTRIDE])
 
 struct RenderConsts {
     int32_t W, H, x0, y0, w, h;
@@ -105,9 +107,16 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
         }
     }
     if (COUNT) {
-        atomicAdd(&counters->interior, (unsigned long long)cnt.interior);
-        atomicAdd(&counters->tris, (unsigned long long)cnt.tris);
-        atomicAdd(&counters->roots, (unsigned long long)cnt.roots);
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt.interior += __shfl_down(cnt.interior, off);
+            cnt.tris += __shfl_down(cnt.tris, off);
+            cnt.roots += __shfl_down(cnt.roots, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters->interior, (unsigned long long)cnt.interior);
+            atomicAdd(&counters->tris, (unsigned long long)cnt.tris);
+            atomicAdd(&counters->roots, (unsigned long long)cnt.roots);
+        }
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (ANY)
@@ -127,21 +136,45 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 //     processed once all lanes have reached one, then lanes whose mesh is finished pick their next primitive;
 //   * the wave-uniform phase-A filter uses the cheap slab test (b-O)*RN(1/D) with a widened reject margin, which
 //     can only over-accept; the exact Bounds::Intersect is re-run per lane where the reference runs it.
-#define AGPT_REFILL 20
+#define AGPT_REFILL 32
+// per-primitive root record staged in LDS: [2k] = (bmin.xyz | sphere centre.xyz, kind), [2k+1] = (bmax.xyz, root_enc) |
+// (r2, -, -, -); kind 0 = mesh, 1 = sphere, 2 = empty mesh (never hit)
 
 template <bool ANY>
 __global__ void __launch_bounds__(AGPT_BLOCK)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-             DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters) {
+             DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters,
+             int refill) {
     __shared__ uint32_t s_stack[AGPT_STACK_DEPTH * AGPT_BLOCK];
+    __shared__ float4 s_prim[2 * 64];
     uint32_t* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
     const int n_prims = sc.n_prims;
+    if ((int)threadIdx.x < n_prims) {
+        const DevPrim& P = sc.prims[threadIdx.x];
+        float4 a, b;
+        if (P.type == AGPT_PRIM_SPHERE) {
+            a.x = P.cx; a.y = P.cy; a.z = P.cz; a.w = 1.f;
+            b.x = P.r2; b.y = 0.f; b.z = 0.f; b.w = 0.f;
+        } else {
+            a.x = P.root_bmin[0]; a.y = P.root_bmin[1]; a.z = P.root_bmin[2]; a.w = P.n_tris > 0 ? 0.f : 2.f;
+            b.x = P.root_bmax[0]; b.y = P.root_bmax[1]; b.z = P.root_bmax[2]; b.w = __uint_as_float(P.root_enc);
+        }
+        s_prim[2 * threadIdx.x] = a;
+        s_prim[2 * threadIdx.x + 1] = b;
+    }
+    __syncthreads();
     const unsigned long long all_prims = n_prims >= 64 ? ~0ull : ((1ull << n_prims) - 1ull);
 
+    // work is reserved in ranges of `chunk` rays per atomic (a wave-private [next, end) window) and handed to idle
+    // lanes from there: one same-address atomic costs ~11 ns chip-wide, so per-refill atomics would cap the kernel
+    // at ~88 M refills/s.  The range shrinks for short queues so late, small launches still spread over the chip.
+    // Refills draw from ONE moving queue frontier (one atomic per refill): at any moment the whole chip traces rays
+    // that are neighbours in the queue (neighbouring pixels / path ids), which keeps their BVH nodes hot in the L2s.
+    // Reserving large private ranges per wave instead measured 8 % slower (A/B on MI355X, same process).
     bool active = false, in_mesh = false;
     bool exhausted = false;  // wave-uniform
     uint32_t pid = 0, cur = 0, hid = AGPT_HIT_MISS;
@@ -158,7 +191,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         // ---- refill ---------------------------------------------------------------------------------------
         unsigned long long act = __ballot(active);
         int n_active = __popcll(act);
-        if (!exhausted && n_active <= 64 - AGPT_REFILL) {
+        if (!exhausted && n_active <= 64 - refill) {
             const int n_idle = 64 - n_active;
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(work_head, (uint32_t)n_idle);
@@ -185,19 +218,19 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                 // phase A: conservative per-primitive filter at the initial t (wave-uniform loop)
                 unsigned long long m = 0;
                 for (int k = 0; k < n_prims; ++k) {
-                    const DevPrim& P = sc.prims[k];
+                    const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
                     bool h;
-                    if (P.type == AGPT_PRIM_SPHERE) {
+                    if (pa.w == 1.f) {
                         float root;
-                        h = sphere_test(P, r, rayt, root);
+                        h = sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, r, rayt, root);
                     } else {
-                        float t0x = (P.root_bmin[0] - r.O.x) * r.R.x, t1x = (P.root_bmax[0] - r.O.x) * r.R.x;
-                        float t0y = (P.root_bmin[1] - r.O.y) * r.R.y, t1y = (P.root_bmax[1] - r.O.y) * r.R.y;
-                        float t0z = (P.root_bmin[2] - r.O.z) * r.R.z, t1z = (P.root_bmax[2] - r.O.z) * r.R.z;
+                        float t0x = (pa.x - r.O.x) * r.R.x, t1x = (pb2.x - r.O.x) * r.R.x;
+                        float t0y = (pa.y - r.O.y) * r.R.y, t1y = (pb2.y - r.O.y) * r.R.y;
+                        float t0z = (pa.z - r.O.z) * r.R.z, t1z = (pb2.z - r.O.z) * r.R.z;
                         float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
                         float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), rayt));
                         // exact test rejects iff tmax*1.00000024 < tmin; products are within 2 ulp of the quotients
-                        h = P.n_tris > 0 && !(tmax * 1.000002f < tmin);
+                        h = pa.w == 0.f && !(tmax * 1.000002f < tmin);
                     }
                     m |= (unsigned long long)(h ? 1u : 0u) << k;
                 }
@@ -227,10 +260,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                 }
                 const int k = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
-                const DevPrim& P = sc.prims[k];
-                if (P.type == AGPT_PRIM_SPHERE) {
+                const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
+                if (pa.w == 1.f) {
                     float root;
-                    if (sphere_test(P, r, rayt, root)) {
+                    if (sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, r, rayt, root)) {
                         if (ANY) {
                             occluded[pid] = 1u;
                             active = false;
@@ -243,11 +276,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                     continue;
                 }
+                if (pa.w != 0.f) continue;
                 float dist;
-                if (!box_test(P.root_bmin[0], P.root_bmin[1], P.root_bmin[2], P.root_bmax[0], P.root_bmax[1], P.root_bmax[2],
-                              r, rayt, dist))
-                    continue;
-                cur = P.root_enc;
+                if (!box_test(pa.x, pa.y, pa.z, pb2.x, pb2.y, pb2.z, r, rayt, dist)) continue;
+                cur = __float_as_uint(pb2.w);
                 sp = 0;
                 in_mesh = true;
             }
@@ -317,7 +349,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             }
             act = __ballot(active);
             if (act == 0) break;
-            if (!exhausted && __popcll(act) <= 64 - AGPT_REFILL) break;
+            if (!exhausted && __popcll(act) <= 64 - refill) break;
         }
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -408,238 +440,309 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
     q.active[i] = i;
     q.ext[i] = i;
     if (i == 0) {
-        q.counts[0] = total;
-        q.counts[1] = total;
-        q.counts[2] = 0;
-        q.counts[3] = 0;
+        QCOUNT(q, 0) = total;
+        QCOUNT(q, 1) = total;
+        QCOUNT(q, 2) = 0;
+        QCOUNT(q, 3) = 0;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// PathTracer::Li's loop body (integrator.h:132-188) in wavefront form.
-__global__ void __launch_bounds__(AGPT_BLOCK)
-k_shade(DevScene sc, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout, DevCounters* __restrict__ counters) {
-    const uint32_t n_active = qin.counts[0];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    // all lanes of a wave iterate together so the ballots in queue_push see every lane
-    const uint32_t n_round = (n_active + 63u) & ~63u;
-    uint32_t shaded = 0;
-    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < n_round; qi += stride) {
-        const bool valid = qi < n_active;
-        bool push_active = false, push_ext = false, push_mis = false, push_shadow = false;
-        uint32_t pid = 0;
-        if (valid) {
-            pid = qin.active[qi];
-            float4 b4 = pb.beta4[pid];
-            float4 l4 = pb.L4[pid];
-            v3 beta = V3(b4.x, b4.y, b4.z);
-            v3 L = V3(l4.x, l4.y, l4.z);
-            uint32_t flags = __float_as_uint(b4.w);
-            uint32_t rng = __float_as_uint(l4.w);
+// PathTracer::Li's loop body (integrator.h:132-188) in wavefront form, for one path.  Returns which of the next
+// iteration's queues the path goes to.
+#define SB_ACTIVE 1u
+#define SB_EXT 2u
+#define SB_MIS 4u
+#define SB_SHADOW 8u
+#define SB_SHADED 16u
 
-            // ---- resolve the previous vertex' UniformSampleOneLight (integrator.h:38-105) ------------------
-            if (flags & PF_PENDING) {
-                float4 f4 = pb.fac4[pid];
-                v3 Ld = V3s(0.f);
-                if (flags & PF_PEND_C1) {
-                    if (!pb.occluded[pid]) {  // VisibilityTester::Unoccluded, lights.cpp:10-12
-                        float4 c = pb.c1[pid];
-                        Ld = Ld + V3(c.x, c.y, c.z);
-                    }
-                }
-                if (flags & PF_PEND_C2) {
-                    uint32_t light = __float_as_uint(f4.w);
-                    uint32_t hid = pb.mis_hit[pid].id;
-                    bool add;
-                    if (hid != AGPT_HIT_MISS) {  // integrator.h:82-85: hit shape's area light must be the sampled light
-                        int hp = (hid & AGPT_HIT_SPHERE) ? (int)(hid & 0x7FFFFFFFu)
-                                                         : (int)__float_as_uint(sc.tri_shade[4 * (size_t)hid + 3].w);
-                        add = sc.prims[hp].arealight == (int)light;
-                    } else {  // :86-87 light.Le(ray): non-zero only for the infinite light
-                        add = sc.lights[light].type == AGPT_LIGHT_UNIFORM_INFINITE;
-                    }
-                    if (add) {
-                        float4 c = pb.c2[pid];
-                        Ld = Ld + V3(c.x, c.y, c.z);
-                    }
-                }
-                float lightPdf = 1.f / sc.n_lights;           // integrator.h:100,104
-                L = L + beta * (Ld / lightPdf);               // integrator.h:166
-                if (!(flags & PF_DEAD)) beta = beta * V3(f4.x, f4.y, f4.z);  // integrator.h:176
-                flags &= ~(PF_PENDING | PF_PEND_C1 | PF_PEND_C2);
+__device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderConsts& rc, const PathBuffers& pb, uint32_t pid) {
+    uint32_t bits = 0;
+    float4 b4 = pb.beta4[pid];
+    float4 l4 = pb.L4[pid];
+    v3 beta = V3(b4.x, b4.y, b4.z);
+    v3 L = V3(l4.x, l4.y, l4.z);
+    uint32_t flags = __float_as_uint(b4.w);
+    uint32_t rng = __float_as_uint(l4.w);
+
+    // ---- resolve the previous vertex' UniformSampleOneLight (integrator.h:38-105) ------------------
+    if (flags & PF_PENDING) {
+        float4 f4 = pb.fac4[pid];
+        v3 Ld = V3s(0.f);
+        if (flags & PF_PEND_C1) {
+            if (!pb.occluded[pid]) {  // VisibilityTester::Unoccluded, lights.cpp:10-12
+                float4 c = pb.c1[pid];
+                Ld = Ld + V3(c.x, c.y, c.z);
             }
+        }
+        if (flags & PF_PEND_C2) {
+            uint32_t light = __float_as_uint(f4.w);
+            uint32_t hid = pb.mis_hit[pid].id;
+            bool add;
+            if (hid != AGPT_HIT_MISS) {  // integrator.h:82-85: hit shape's area light must be the sampled light
+                int hp = (hid & AGPT_HIT_SPHERE) ? (int)(hid & 0x7FFFFFFFu)
+                                                 : (int)__float_as_uint(sc.tri_shade[4 * (size_t)hid + 3].w);
+                add = sc.prims[hp].arealight == (int)light;
+            } else {  // :86-87 light.Le(ray): non-zero only for the infinite light
+                add = sc.lights[light].type == AGPT_LIGHT_UNIFORM_INFINITE;
+            }
+            if (add) {
+                float4 c = pb.c2[pid];
+                Ld = Ld + V3(c.x, c.y, c.z);
+            }
+        }
+        float lightPdf = 1.f / sc.n_lights;           // integrator.h:100,104
+        L = L + beta * (Ld / lightPdf);               // integrator.h:166
+        if (!(flags & PF_DEAD)) beta = beta * V3(f4.x, f4.y, f4.z);  // integrator.h:176
+        flags &= ~(PF_PENDING | PF_PEND_C1 | PF_PEND_C2);
+    }
 
-            if (!(flags & PF_DEAD)) {
-                uint32_t bounces = flags & PF_BOUNCE_MASK;
-                DevHit h = pb.hit[pid];
-                float4 o4 = pb.ext_o[pid], d4 = pb.ext_d[pid];
-                v3 O = V3(o4.x, o4.y, o4.z), D = V3(d4.x, d4.y, d4.z);
-                const bool found = h.id != AGPT_HIT_MISS;
-                Surface s;
-                if (found) {
-                    if (h.id & AGPT_HIT_SPHERE)
-                        surface_from_sphere(sc, (int)(h.id & 0x7FFFFFFFu), O, D, h.t, s);
-                    else
-                        surface_from_triangle(sc, h.id, h.b1, h.b2, O, D, h.t, s);
-                }
-                // integrator.h:139-147
-                if (bounces == 0 || (flags & PF_SPECULAR)) {
-                    if (found) {
-                        int al = sc.prims[s.prim].arealight;
-                        v3 Le = al >= 0 ? mat_v3(sc.lights[al].L) : V3s(0.f);
-                        L = L + beta * Le;
+    if (!(flags & PF_DEAD)) {
+        uint32_t bounces = flags & PF_BOUNCE_MASK;
+        DevHit h = pb.hit[pid];
+        float4 o4 = pb.ext_o[pid], d4 = pb.ext_d[pid];
+        v3 O = V3(o4.x, o4.y, o4.z), D = V3(d4.x, d4.y, d4.z);
+        const bool found = h.id != AGPT_HIT_MISS;
+        Surface s;
+        if (found) {
+            if (h.id & AGPT_HIT_SPHERE)
+                surface_from_sphere(sc, (int)(h.id & 0x7FFFFFFFu), O, D, h.t, s);
+            else
+                surface_from_triangle(sc, h.id, h.b1, h.b2, O, D, h.t, s);
+        }
+        // integrator.h:139-147
+        if (bounces == 0 || (flags & PF_SPECULAR)) {
+            if (found) {
+                int al = sc.prims[s.prim].arealight;
+                v3 Le = al >= 0 ? mat_v3(sc.lights[al].L) : V3s(0.f);
+                L = L + beta * Le;
+            } else {
+                for (int li = 0; li < sc.n_lights; li++)
+                    if (sc.lights[li].type == AGPT_LIGHT_UNIFORM_INFINITE) L = L + beta * mat_v3(sc.lights[li].L);
+            }
+        }
+        if (!found || (int)bounces >= rc.max_depth) {  // :150
+            flags |= PF_DEAD;
+        } else if (sc.prims[s.prim].material < 0) {
+            // :152-161 null material: skip the surface, re-cast without counting a bounce
+            v3 nO = s.p + AGPT_EPSILON * D;
+            v3 nD = normalize(D);
+            float4 no4, nd4;
+            no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
+            nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
+            pb.ext_o[pid] = no4;
+            pb.ext_d[pid] = nd4;
+            bits |= SB_EXT;
+        } else {
+            bits |= SB_SHADED;
+            const DevMaterial& m = sc.materials[sc.prims[s.prim].material];
+            Bsdf bsdf;
+            bsdf_setup(bsdf, m, s.n, s.ns, s.ss_bsdf);
+            // ---- UniformSampleOneLight / EstimateDirect (integrator.h:38-105) -------------------
+            const bool do_nee = !bsdf_is_perfectly_specular(bsdf) && sc.n_lights > 0;
+            int numLight = 0;
+            float uS0 = 0.f, uS1 = 0.f;
+            float scatteringPdf = 0;
+            v3 wi = V3s(0.f);
+            if (do_nee) {
+                int nLights = sc.n_lights;
+                numLight = (int)(rng_float(rng) * nLights);
+                if (nLights - 1 < numLight) numLight = nLights - 1;
+                float uL0 = rng_float(rng), uL1 = rng_float(rng);
+                uS0 = rng_float(rng);
+                uS1 = rng_float(rng);
+                const DevLight& light = sc.lights[numLight];
+                flags |= PF_PENDING;
+                float lightPdf = 0;
+                v3 Li;
+                v3 visO = V3s(0.f), visD = V3(0, 0, 1);
+                float visT = 0;
+                if (light.type == AGPT_LIGHT_UNIFORM_INFINITE) {  // lights.cpp:15-24 (quirk 3)
+                    wi = random_in_hemisphere(rng, s.ns);
+                    lightPdf = AGPT_INV2PI;
+                    visO = s.p + AGPT_EPSILON * wi;
+                    visD = normalize(wi);
+                    visT = AGPT_FLT_MAX;
+                    Li = mat_v3(light.L);
+                } else {  // AreaLight::Sample_Li lights.cpp:115-126
+                    v3 pS;
+                    sphere_sample_ref(sc.prims[light.shape], s.p, uL0, uL1, &pS, &lightPdf);
+                    if (lightPdf == 0 || sqrlen(pS - s.p) == 0) {
+                        lightPdf = 0;
+                        Li = V3s(0.f);
                     } else {
-                        for (int li = 0; li < sc.n_lights; li++)
-                            if (sc.lights[li].type == AGPT_LIGHT_UNIFORM_INFINITE) L = L + beta * mat_v3(sc.lights[li].L);
+                        wi = pS - s.p;
+                        float dist = length(wi);
+                        wi = wi / dist;
+                        visO = s.p + AGPT_EPSILON * wi;
+                        visD = normalize(wi);
+                        visT = dist - 10 * AGPT_EPSILON;
+                        Li = mat_v3(light.L);
                     }
                 }
-                if (!found || (int)bounces >= rc.max_depth) {  // :150
+                if (lightPdf > 0 && !isblack(Li)) {  // integrator.h:44-60
+                    v3 f;
+                    bsdf_f_pdf(bsdf, m, s.wo, wi, true, &f, &scatteringPdf);
+                    f = f * absdot(wi, s.ns);
+                    if (!isblack(f)) {
+                        float weight = power_heuristic(1, lightPdf, 1, scatteringPdf);
+                        v3 c1 = f * Li * weight / lightPdf;
+                        float4 c4, so4, sd4;
+                        c4.x = c1.x; c4.y = c1.y; c4.z = c1.z; c4.w = 0.f;
+                        so4.x = visO.x; so4.y = visO.y; so4.z = visO.z; so4.w = visT;
+                        sd4.x = visD.x; sd4.y = visD.y; sd4.z = visD.z; sd4.w = 0.f;
+                        pb.c1[pid] = c4;
+                        pb.sh_o[pid] = so4;
+                        pb.sh_d[pid] = sd4;
+                        flags |= PF_PEND_C1;
+                        bits |= SB_SHADOW;
+                    }
+                }
+            }
+            // ---- the two BSDF-sampling legs share one copy of the code: leg 0 = EstimateDirect's MIS leg
+            // (integrator.h:63-90, uScattering, skipSpecular), leg 1 = the continuation (integrator.h:170-187)
+            v3 fac = V3s(1.f);
+#pragma unroll 1
+            for (int leg = do_nee ? 0 : 1; leg < 2; ++leg) {
+                float u0, u1;
+                float pdf = 0;
+                if (leg == 0) {
+                    u0 = uS0;
+                    u1 = uS1;
+                    pdf = scatteringPdf;  // EstimateDirect reuses its scatteringPdf variable (quirk 9)
+                } else {
+                    wi = V3s(0.f);
+                    u0 = rng_float(rng);
+                    u1 = rng_float(rng);
+                }
+                bool sampledSpecular = false;
+                v3 f = bsdf_sample_f(bsdf, m, s.wo, &wi, u0, u1, &pdf, leg == 0, &sampledSpecular);
+                if (leg == 0) {
+                    const DevLight& light = sc.lights[numLight];
+                    f = f * absdot(wi, s.ns);
+                    if (!isblack(f) && pdf > 0) {
+                        float lp;
+                        if (light.type == AGPT_LIGHT_UNIFORM_INFINITE)
+                            lp = dot(s.n, wi) > 0 ? AGPT_INV2PI : 0.f;  // lights.cpp:26-28 (geometric n)
+                        else
+                            lp = sphere_pdf(sc.prims[light.shape], s.p);
+                        if (lp != 0) {
+                            float weight = power_heuristic(1, pdf, 1, lp);
+                            v3 Li2 = mat_v3(light.L);  // Le(-wi) of the light's shape, or light.Le(ray) on a miss
+                            if (!isblack(Li2)) {
+                                v3 c2 = f * Li2 * weight / pdf;
+                                v3 mO = s.p + AGPT_EPSILON * wi;
+                                v3 mD = normalize(wi);
+                                float4 c4, mo4, md4;
+                                c4.x = c2.x; c4.y = c2.y; c4.z = c2.z; c4.w = 0.f;
+                                mo4.x = mO.x; mo4.y = mO.y; mo4.z = mO.z; mo4.w = AGPT_FLT_MAX;
+                                md4.x = mD.x; md4.y = mD.y; md4.z = mD.z; md4.w = 0.f;
+                                pb.c2[pid] = c4;
+                                pb.mis_o[pid] = mo4;
+                                pb.mis_d[pid] = md4;
+                                flags |= PF_PEND_C2;
+                                bits |= SB_MIS;
+                            }
+                        }
+                    }
+                } else if (isblack(f) || pdf == 0) {
                     flags |= PF_DEAD;
-                } else if (sc.prims[s.prim].material < 0) {
-                    // :152-161 null material: skip the surface, re-cast without counting a bounce
-                    v3 nO = s.p + AGPT_EPSILON * D;
-                    v3 nD = normalize(D);
+                } else {
+                    fac = f * absdot(wi, s.ns) / pdf;
+                    if (!(flags & PF_PENDING)) beta = beta * fac;
+                    flags = (flags & ~PF_SPECULAR) | (sampledSpecular ? PF_SPECULAR : 0u);
+                    flags = (flags & ~PF_BOUNCE_MASK) | ((bounces + 1) & PF_BOUNCE_MASK);
+                    v3 nO = s.p + AGPT_EPSILON * wi;
+                    v3 nD = normalize(wi);
                     float4 no4, nd4;
                     no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
                     nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
                     pb.ext_o[pid] = no4;
                     pb.ext_d[pid] = nd4;
-                    push_ext = true;
-                } else {
-                    shaded++;
-                    const DevMaterial& m = sc.materials[sc.prims[s.prim].material];
-                    Bsdf bsdf;
-                    bsdf_setup(bsdf, m, s.n, s.ns, s.ss_bsdf);
-                    // ---- UniformSampleOneLight / EstimateDirect (integrator.h:38-105) -------------------
-                    if (!bsdf_is_perfectly_specular(bsdf) && sc.n_lights > 0) {
-                        int nLights = sc.n_lights;
-                        int numLight = (int)(rng_float(rng) * nLights);
-                        if (nLights - 1 < numLight) numLight = nLights - 1;
-                        float uL0 = rng_float(rng), uL1 = rng_float(rng);
-                        float uS0 = rng_float(rng), uS1 = rng_float(rng);
-                        const DevLight& light = sc.lights[numLight];
-                        flags |= PF_PENDING;
-                        v3 wi = V3s(0.f);
-                        float lightPdf = 0, scatteringPdf = 0;
-                        v3 Li;
-                        v3 visO = V3s(0.f), visD = V3(0, 0, 1);
-                        float visT = 0;
-                        if (light.type == AGPT_LIGHT_UNIFORM_INFINITE) {  // lights.cpp:15-24 (quirk 3)
-                            wi = random_in_hemisphere(rng, s.ns);
-                            lightPdf = AGPT_INV2PI;
-                            visO = s.p + AGPT_EPSILON * wi;
-                            visD = normalize(wi);
-                            visT = AGPT_FLT_MAX;
-                            Li = mat_v3(light.L);
-                        } else {  // AreaLight::Sample_Li lights.cpp:115-126
-                            v3 pS;
-                            sphere_sample_ref(sc.prims[light.shape], s.p, uL0, uL1, &pS, &lightPdf);
-                            if (lightPdf == 0 || sqrlen(pS - s.p) == 0) {
-                                lightPdf = 0;
-                                Li = V3s(0.f);
-                            } else {
-                                wi = pS - s.p;
-                                float dist = length(wi);
-                                wi = wi / dist;
-                                visO = s.p + AGPT_EPSILON * wi;
-                                visD = normalize(wi);
-                                visT = dist - 10 * AGPT_EPSILON;
-                                Li = mat_v3(light.L);
-                            }
-                        }
-                        if (lightPdf > 0 && !isblack(Li)) {  // integrator.h:44-60
-                            v3 f = bsdf_f(bsdf, m, s.wo, wi, true) * absdot(wi, s.ns);
-                            scatteringPdf = bsdf_pdf(bsdf, m, s.wo, wi, true);
-                            if (!isblack(f)) {
-                                float weight = power_heuristic(1, lightPdf, 1, scatteringPdf);
-                                v3 c1 = f * Li * weight / lightPdf;
-                                float4 c4, so4, sd4;
-                                c4.x = c1.x; c4.y = c1.y; c4.z = c1.z; c4.w = 0.f;
-                                so4.x = visO.x; so4.y = visO.y; so4.z = visO.z; so4.w = visT;
-                                sd4.x = visD.x; sd4.y = visD.y; sd4.z = visD.z; sd4.w = 0.f;
-                                pb.c1[pid] = c4;
-                                pb.sh_o[pid] = so4;
-                                pb.sh_d[pid] = sd4;
-                                flags |= PF_PEND_C1;
-                                push_shadow = true;
-                            }
-                        }
-                        {  // integrator.h:63-90 BSDF-sampling leg
-                            v3 f = bsdf_sample_f(bsdf, m, s.wo, &wi, uS0, uS1, &scatteringPdf, true, nullptr);
-                            f = f * absdot(wi, s.ns);
-                            if (!isblack(f) && scatteringPdf > 0) {
-                                float lp;
-                                if (light.type == AGPT_LIGHT_UNIFORM_INFINITE)
-                                    lp = dot(s.n, wi) > 0 ? AGPT_INV2PI : 0.f;  // lights.cpp:26-28 (geometric n)
-                                else
-                                    lp = sphere_pdf(sc.prims[light.shape], s.p);
-                                if (lp != 0) {
-                                    float weight = power_heuristic(1, scatteringPdf, 1, lp);
-                                    v3 Li2 = mat_v3(light.L);  // Le(-wi) of the light's shape, or light.Le(ray) on a miss
-                                    if (!isblack(Li2)) {
-                                        v3 c2 = f * Li2 * weight / scatteringPdf;
-                                        v3 mO = s.p + AGPT_EPSILON * wi;
-                                        v3 mD = normalize(wi);
-                                        float4 c4, mo4, md4;
-                                        c4.x = c2.x; c4.y = c2.y; c4.z = c2.z; c4.w = 0.f;
-                                        mo4.x = mO.x; mo4.y = mO.y; mo4.z = mO.z; mo4.w = AGPT_FLT_MAX;
-                                        md4.x = mD.x; md4.y = mD.y; md4.z = mD.z; md4.w = 0.f;
-                                        pb.c2[pid] = c4;
-                                        pb.mis_o[pid] = mo4;
-                                        pb.mis_d[pid] = md4;
-                                        flags |= PF_PEND_C2;
-                                        push_mis = true;
-                                    }
-                                }
-                            }
-                        }
-                        // the chosen light rides in fac4.w
-                        float4 f4;
-                        f4.x = 1.f; f4.y = 1.f; f4.z = 1.f; f4.w = __uint_as_float((uint32_t)numLight);
-                        pb.fac4[pid] = f4;
-                    }
-                    // ---- sample the BSDF for the next direction (integrator.h:170-187) -----------------
-                    v3 wi = V3s(0.f);
-                    float u0 = rng_float(rng), u1 = rng_float(rng);
-                    float pdf = 0;
-                    bool sampledSpecular = false;
-                    v3 f = bsdf_sample_f(bsdf, m, s.wo, &wi, u0, u1, &pdf, false, &sampledSpecular);
-                    if (isblack(f) || pdf == 0) {
-                        flags |= PF_DEAD;
-                    } else {
-                        v3 fac = f * absdot(wi, s.ns) / pdf;
-                        if (flags & PF_PENDING) {
-                            float4 f4 = pb.fac4[pid];
-                            f4.x = fac.x; f4.y = fac.y; f4.z = fac.z;
-                            pb.fac4[pid] = f4;
-                        } else {
-                            beta = beta * fac;
-                        }
-                        flags = (flags & ~PF_SPECULAR) | (sampledSpecular ? PF_SPECULAR : 0u);
-                        flags = (flags & ~PF_BOUNCE_MASK) | ((bounces + 1) & PF_BOUNCE_MASK);
-                        v3 nO = s.p + AGPT_EPSILON * wi;
-                        v3 nD = normalize(wi);
-                        float4 no4, nd4;
-                        no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
-                        nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
-                        pb.ext_o[pid] = no4;
-                        pb.ext_d[pid] = nd4;
-                        push_ext = true;
-                    }
+                    bits |= SB_EXT;
                 }
             }
-            push_active = push_ext || (flags & PF_PENDING);
-            b4.x = beta.x; b4.y = beta.y; b4.z = beta.z; b4.w = __uint_as_float(flags);
-            l4.x = L.x; l4.y = L.y; l4.z = L.z; l4.w = __uint_as_float(rng);
-            pb.beta4[pid] = b4;
-            pb.L4[pid] = l4;
+            if (flags & PF_PENDING) {  // the continuation factor and the chosen light wait for the resolve
+                float4 f4;
+                f4.x = fac.x; f4.y = fac.y; f4.z = fac.z; f4.w = __uint_as_float((uint32_t)numLight);
+                pb.fac4[pid] = f4;
+            }
         }
-        queue_push(qout.active, &qout.counts[0], push_active, pid);
-        queue_push(qout.ext, &qout.counts[1], push_ext, pid);
-        queue_push(qout.mis, &qout.counts[2], push_mis, pid);
-        queue_push(qout.shadow, &qout.counts[3], push_shadow, pid);
     }
-    if (shaded) atomicAdd(&counters->shaded, (unsigned long long)shaded);
+    if ((bits & SB_EXT) || (flags & PF_PENDING)) bits |= SB_ACTIVE;
+    b4.x = beta.x; b4.y = beta.y; b4.z = beta.z; b4.w = __uint_as_float(flags);
+    l4.x = L.x; l4.y = L.y; l4.z = L.z; l4.w = __uint_as_float(rng);
+    pb.beta4[pid] = b4;
+    pb.L4[pid] = l4;
+    return bits;
+}
+
+// One block handles tiles of AGPT_BLOCK*SHADE_U queue entries.  Queue appends are aggregated per tile: ballots give
+// per-wave counts, one thread per queue scans them and reserves the tile's slots with ONE atomic, then every lane
+// writes its path id at its (order-preserving) offset -- 4 atomics per 1024 paths instead of 4 per wave: same-line
+// atomics serialise at ~11 ns each and were the kernel's bottleneck.
+#define SHADE_U 4
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_shade(DevScene sc, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout, DevCounters* __restrict__ counters) {
+    __shared__ uint32_t s_pid[SHADE_U][AGPT_BLOCK];
+    __shared__ uint32_t s_bits[SHADE_U][AGPT_BLOCK];
+    __shared__ uint32_t s_cnt[4][SHADE_U * 4];
+    __shared__ uint32_t s_off[4][SHADE_U * 4];
+    const uint32_t n_active = QCOUNT(qin, 0);
+    const uint32_t tile_size = AGPT_BLOCK * SHADE_U;
+    const uint32_t n_tiles = (n_active + tile_size - 1) / tile_size;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t shaded = 0;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll 1
+        for (int u = 0; u < SHADE_U; ++u) {
+            const uint32_t qi = tile * tile_size + (uint32_t)u * AGPT_BLOCK + (uint32_t)tid;
+            uint32_t pid = 0, bits = 0;
+            if (qi < n_active) {
+                pid = qin.active[qi];
+                bits = shade_path(sc, rc, pb, pid);
+            }
+            s_pid[u][tid] = pid;
+            s_bits[u][tid] = bits;
+            shaded += (bits & SB_SHADED) ? 1u : 0u;
+        }
+        for (int u = 0; u < SHADE_U; ++u) {
+            const uint32_t bits = s_bits[u][tid];
+            for (int q = 0; q < 4; ++q) {
+                unsigned long long m = __ballot((bits >> q) & 1u);
+                if (lane == 0) s_cnt[q][u * 4 + wave] = (uint32_t)__popcll(m);
+            }
+        }
+        __syncthreads();
+        if (tid < 4) {
+            uint32_t run = 0;
+            uint32_t offs[SHADE_U * 4];
+            for (int k = 0; k < SHADE_U * 4; ++k) {
+                offs[k] = run;
+                run += s_cnt[tid][k];
+            }
+            uint32_t base = run ? atomicAdd(&QCOUNT(qout, tid), run) : 0u;
+            for (int k = 0; k < SHADE_U * 4; ++k) s_off[tid][k] = base + offs[k];
+        }
+        __syncthreads();
+        for (int u = 0; u < SHADE_U; ++u) {
+            const uint32_t bits = s_bits[u][tid];
+            const uint32_t pid = s_pid[u][tid];
+            for (int q = 0; q < 4; ++q) {
+                const bool pred = (bits >> q) & 1u;
+                unsigned long long m = __ballot(pred);
+                if (pred) {
+                    uint32_t* qq = q == 0 ? qout.active : (q == 1 ? qout.ext : (q == 2 ? qout.mis : qout.shadow));
+                    qq[s_off[q][u * 4 + wave] + (uint32_t)__popcll(m & lt_mask)] = pid;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // one atomic per wave, not per lane
+    for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
+    if (lane == 0 && shaded) atomicAdd(&counters->shaded, (unsigned long long)shaded);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -664,7 +767,7 @@ k_accumulate(RenderConsts rc, PathBuffers pb, float4* __restrict__ accum, DevCou
         a.z += clr.z;
     }
     accum[ai] = a;
-    if (bad) atomicAdd(&counters->outliers, (unsigned long long)bad);
+    if (bad) atomicAdd(&counters->outliers, (unsigned long long)bad);  // outliers are rare
 }
 
 // Accumulator::CopyToSurface (myapp.h:34-41) with lin2rgb / rgb2uint (template/common.h:41-51)

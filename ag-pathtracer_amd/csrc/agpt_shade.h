@@ -177,49 +177,137 @@ __device__ __forceinline__ v3 disney_fresnel(const DevMaterial& m, float cosI) {
     v3 frs = lerp3(schlick_weight(cosI), mat_v3(m.R0), V3s(1.f));
     return lerp3(m.metallic, V3s(fr_dielectric(cosI, 1, m.eta)), frs);
 }
-__device__ __forceinline__ v3 lobe_f(const DevMaterial& m, int lobe, v3 wo, v3 wi) {
-    if (lobe == LOBE_DIFFUSE) {  // DisneyDiffuse::f disney.h:28-35
+// ---- lobes ------------------------------------------------------------------------------------------------
+// A BSDF is the reference's bxdfs[] list in its fixed insertion order (material.h:51-58,79-81):
+// DisneyDiffuse, DisneyRetro, MicrofacetReflection | SpecularReflection -> a 4-bit mask, bit = lobe id.
+#define LOBE_BIT(l) (1u << (l))
+
+struct LobeEval {
+    v3 f;
+    float pdf;
+};
+
+// f(wo,wi) and Pdf(wo,wi) of one lobe in the local frame.  Evaluating both together lets the microfacet lobe share
+// wh, D(wh) and G1(wo) between MicrofacetReflection::f (reflection.h:42-54) and ::Pdf (:67-71): wi+wo and wo+wi, and
+// the two D / G1 calls of the reference, are the same fp32 values, so sharing them does not change a bit.
+__device__ __forceinline__ LobeEval lobe_eval(const DevMaterial& m, int lobe, v3 wo, v3 wi) {
+    LobeEval e;
+    e.f = V3s(0.f);
+    e.pdf = 0.f;
+    if (lobe == LOBE_DIFFUSE) {  // DisneyDiffuse::f disney.h:28-35; BxDF::Pdf reflection.h:16-18
         float Fo = schlick_weight(AbsCosTheta(wo)), Fi = schlick_weight(AbsCosTheta(wi));
-        return mat_v3(m.diffuse_R) * AGPT_INVPI * (1 - Fo / 2) * (1 - Fi / 2);
-    }
-    if (lobe == LOBE_RETRO) {  // DisneyRetro::f disney.h:43-55
+        e.f = mat_v3(m.diffuse_R) * AGPT_INVPI * (1 - Fo / 2) * (1 - Fi / 2);
+        e.pdf = same_hemisphere(wo, wi) ? AbsCosTheta(wi) * AGPT_INVPI : 0;
+    } else if (lobe == LOBE_RETRO) {  // DisneyRetro::f disney.h:43-55
+        e.pdf = same_hemisphere(wo, wi) ? AbsCosTheta(wi) * AGPT_INVPI : 0;
         v3 wh = wi + wo;
-        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return V3s(0.f);
-        wh = normalize(wh);
-        float cosThetaD = dot(wi, wh);
-        float Fo = schlick_weight(AbsCosTheta(wo)), Fi = schlick_weight(AbsCosTheta(wi));
-        float Rr = 2 * m.roughness * cosThetaD * cosThetaD;
-        return mat_v3(m.diffuse_R) * AGPT_INVPI * Rr * (Fo + Fi + Fo * Fi * (Rr - 1));
-    }
-    if (lobe == LOBE_MICROFACET) {  // MicrofacetReflection::f reflection.h:42-54, G = G1*G1 disney.h:78-81
+        if (!(wh.x == 0 && wh.y == 0 && wh.z == 0)) {
+            wh = normalize(wh);
+            float cosThetaD = dot(wi, wh);
+            float Fo = schlick_weight(AbsCosTheta(wo)), Fi = schlick_weight(AbsCosTheta(wi));
+            float Rr = 2 * m.roughness * cosThetaD * cosThetaD;
+            e.f = mat_v3(m.diffuse_R) * AGPT_INVPI * Rr * (Fo + Fi + Fo * Fi * (Rr - 1));
+        }
+    } else if (lobe == LOBE_MICROFACET) {
         float cosThetaO = AbsCosTheta(wo), cosThetaI = AbsCosTheta(wi);
-        v3 wh = wi + wo;
-        if (cosThetaI == 0 || cosThetaO == 0) return V3s(0.f);
-        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return V3s(0.f);
-        wh = normalize(wh);
-        v3 F = disney_fresnel(m, dot(wi, faceforward(wh, V3(0, 0, 1))));
-        float G = tr_G1(m, wo) * tr_G1(m, wi);
-        return V3s(1.f) * tr_D(m, wh) * G * F / (4 * cosThetaI * cosThetaO);
+        v3 whs = wi + wo;
+        bool f_ok = !(cosThetaI == 0 || cosThetaO == 0) && !(whs.x == 0 && whs.y == 0 && whs.z == 0);
+        bool pdf_ok = same_hemisphere(wo, wi);
+        if (f_ok || pdf_ok) {
+            v3 wh = normalize(whs);
+            float D = tr_D(m, wh);
+            float G1o = tr_G1(m, wo);
+            if (f_ok) {
+                v3 F = disney_fresnel(m, dot(wi, faceforward(wh, V3(0, 0, 1))));
+                float G = G1o * tr_G1(m, wi);  // DisneyMicrofacetDistribution::G disney.h:78-81
+                e.f = V3s(1.f) * D * G * F / (4 * cosThetaI * cosThetaO);
+            }
+            if (pdf_ok) e.pdf = D * G1o * absdot(wo, wh) / AbsCosTheta(wo) / (4 * dot(wo, wh));
+        }
     }
-    return V3s(0.f);  // SpecularReflection::f reflection.h:26-28
+    // LOBE_SPECULAR: f = 0 (reflection.h:26-28), Pdf = 0 (:30)
+    return e;
 }
-__device__ __forceinline__ float lobe_pdf(const DevMaterial& m, int lobe, v3 wo, v3 wi) {
-    if (lobe == LOBE_DIFFUSE || lobe == LOBE_RETRO)  // BxDF::Pdf reflection.h:16-18
-        return same_hemisphere(wo, wi) ? AbsCosTheta(wi) * AGPT_INVPI : 0;
-    if (lobe == LOBE_MICROFACET) {  // reflection.h:67-71
-        if (!same_hemisphere(wo, wi)) return 0;
-        v3 wh = normalize(wo + wi);
-        return tr_pdf(m, wo, wh) / (4 * dot(wo, wh));
+
+// Sum of f and of Pdf over the lobes of `mask`, in list order: what BSDF::f (reflection.h:114-123, when reflect),
+// BSDF::Pdf (:174-188) and the tail of BSDF::Sample_f (:156-170) compute.  `skip_pdf_lobe` (or -1) is left out of the
+// pdf sum (the sampled lobe contributes the pdf its own Sample_f returned), pdf_init is the running value.
+// One shared, non-inlined copy: keeps k_shade inside the instruction cache.
+__device__ __noinline__ LobeEval bsdf_eval_lobes(const DevMaterial* mp, uint32_t mask, v3 wo, v3 wi, int skip_pdf_lobe,
+                                                 float pdf_init, bool want_f) {
+    const DevMaterial& m = *mp;
+    LobeEval acc;
+    acc.f = V3s(0.f);
+    acc.pdf = pdf_init;
+#pragma unroll 1
+    for (int lobe = 0; lobe < 4; ++lobe) {
+        if (!(mask & LOBE_BIT(lobe))) continue;
+        LobeEval e = lobe_eval(m, lobe, wo, wi);
+        if (want_f) acc.f = acc.f + e.f;
+        if (lobe != skip_pdf_lobe) acc.pdf += e.pdf;
     }
-    return 0;
+    return acc;
 }
-// returns f; *pdf is only written on the paths the reference writes it (quirk 8)
-__device__ __forceinline__ v3 lobe_sample_f(const DevMaterial& m, int lobe, v3 wo, v3* wi, float u0, float u1, float* pdf) {
+
+// ---- BSDF (reflection.cpp:6-11, reflection.h:83-201) --------------------------------------------------------
+struct Bsdf {
+    v3 ng, ns, ss, ts;
+    uint32_t lobes;  // LOBE_BIT mask
+};
+__device__ __forceinline__ void bsdf_setup(Bsdf& b, const DevMaterial& m, v3 ng, v3 ns, v3 shading_dpdu_normalized) {
+    b.ng = ng;
+    b.ns = ns;
+    b.ss = shading_dpdu_normalized;
+    b.ts = cross(ns, b.ss);
+    b.lobes = (m.has_diffuse ? LOBE_BIT(LOBE_DIFFUSE) : 0u) | (m.has_retro ? LOBE_BIT(LOBE_RETRO) : 0u) |
+              (m.has_microfacet ? LOBE_BIT(LOBE_MICROFACET) : 0u) | (m.has_specular ? LOBE_BIT(LOBE_SPECULAR) : 0u);
+}
+__device__ __forceinline__ uint32_t lobes_matching(const Bsdf& b, bool skipSpecular) {
+    return skipSpecular ? (b.lobes & ~LOBE_BIT(LOBE_SPECULAR)) : b.lobes;
+}
+__device__ __forceinline__ v3 w2l(const Bsdf& b, v3 v) { return V3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+__device__ __forceinline__ v3 l2w(const Bsdf& b, v3 v) {
+    return V3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
+              b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
+}
+__device__ __forceinline__ bool bsdf_is_perfectly_specular(const Bsdf& b) {
+    return (b.lobes & ~LOBE_BIT(LOBE_SPECULAR)) == 0;  // vacuously true for an empty list, like the reference's loop
+}
+// BSDF::f and BSDF::Pdf for one (wo, wi) pair (reflection.h:114-123, 174-188)
+__device__ __forceinline__ void bsdf_f_pdf(const Bsdf& b, const DevMaterial& m, v3 woW, v3 wiW, bool skipSpecular, v3* f_out,
+                                           float* pdf_out) {
+    *f_out = V3s(0.f);
+    *pdf_out = 0.f;
+    if (b.lobes == 0) return;
+    v3 wi = w2l(b, wiW), wo = w2l(b, woW);
+    if (wo.z == 0) return;
+    bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+    uint32_t mask = lobes_matching(b, skipSpecular);
+    int matching = __popc(mask);
+    LobeEval e = bsdf_eval_lobes(&m, mask, wo, wi, -1, 0.f, reflect);
+    if (reflect) *f_out = e.f;
+    *pdf_out = matching > 0 ? e.pdf / matching : 0.f;
+}
+__device__ __forceinline__ v3 bsdf_f(const Bsdf& b, const DevMaterial& m, v3 woW, v3 wiW, bool skipSpecular) {
+    v3 f;
+    float pdf;
+    bsdf_f_pdf(b, m, woW, wiW, skipSpecular, &f, &pdf);
+    return f;
+}
+__device__ __forceinline__ float bsdf_pdf(const Bsdf& b, const DevMaterial& m, v3 woW, v3 wiW, bool skipSpecular) {
+    v3 f;
+    float pdf;
+    bsdf_f_pdf(b, m, woW, wiW, skipSpecular, &f, &pdf);
+    return pdf;
+}
+// the chosen lobe's own Sample_f: returns its f (only used for the specular lobe); *pdf is written only on the paths
+// the reference writes it (quirk 8)
+__device__ __forceinline__ v3 lobe_sample(const DevMaterial& m, int lobe, v3 wo, v3* wi, float u0, float u1, float* pdf) {
     if (lobe == LOBE_DIFFUSE || lobe == LOBE_RETRO) {  // BxDF::Sample_f reflection.h:8-15
         *wi = cosine_sample_hemisphere(u0, u1);
         if (wo.z < 0) wi->z *= -1;
-        *pdf = lobe_pdf(m, lobe, wo, *wi);
-        return lobe_f(m, lobe, wo, *wi);
+        *pdf = same_hemisphere(wo, *wi) ? AbsCosTheta(*wi) * AGPT_INVPI : 0;
+        return V3s(1.f);  // value unused: BSDF::Sample_f recomputes f over all lobes
     }
     if (lobe == LOBE_MICROFACET) {  // reflection.h:55-66, Sample_wh microfacet.h:134-140
         if (wo.z == 0) return V3s(0.f);
@@ -230,105 +318,45 @@ __device__ __forceinline__ v3 lobe_sample_f(const DevMaterial& m, int lobe, v3 w
         *wi = reflect3(wo, wh);
         if (!same_hemisphere(wo, *wi)) return V3s(0.f);
         *pdf = tr_pdf(m, wo, wh) / (4 * dot(wo, wh));
-        return lobe_f(m, lobe, wo, *wi);
+        return V3s(1.f);
     }
     // SpecularReflection::Sample_f reflection.cpp:13-18, FresnelNoOp
     *wi = V3(-wo.x, -wo.y, wo.z);
     *pdf = 1;
     return V3s(1.f) * mat_v3(m.mirror_R) / AbsCosTheta(*wi);
 }
-
-// ---- BSDF (reflection.cpp:6-11, reflection.h:83-201) --------------------------------------------------------
-struct Bsdf {
-    v3 ng, ns, ss, ts;
-    int lobes[3];
-    int n;
-};
-__device__ __forceinline__ void bsdf_setup(Bsdf& b, const DevMaterial& m, v3 ng, v3 ns, v3 shading_dpdu_normalized) {
-    b.ng = ng;
-    b.ns = ns;
-    b.ss = shading_dpdu_normalized;
-    b.ts = cross(ns, b.ss);
-    b.n = 0;
-    if (m.has_diffuse) b.lobes[b.n++] = LOBE_DIFFUSE;     // material.h:51-58
-    if (m.has_retro) b.lobes[b.n++] = LOBE_RETRO;
-    if (m.has_microfacet) b.lobes[b.n++] = LOBE_MICROFACET;
-    if (m.has_specular) b.lobes[b.n++] = LOBE_SPECULAR;   // material.h:79-81
-}
-__device__ __forceinline__ bool lobe_matches(int lobe, bool skipSpecular) { return !skipSpecular || lobe != LOBE_SPECULAR; }
-__device__ __forceinline__ v3 w2l(const Bsdf& b, v3 v) { return V3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
-__device__ __forceinline__ v3 l2w(const Bsdf& b, v3 v) {
-    return V3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
-              b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
-}
-__device__ __forceinline__ bool bsdf_is_perfectly_specular(const Bsdf& b) {
-    for (int i = 0; i < b.n; i++)
-        if (b.lobes[i] != LOBE_SPECULAR) return false;
-    return true;
-}
-// BSDF::f reflection.h:114-123
-__device__ __forceinline__ v3 bsdf_f(const Bsdf& b, const DevMaterial& m, v3 woW, v3 wiW, bool skipSpecular) {
-    v3 wi = w2l(b, wiW), wo = w2l(b, woW);
-    if (wo.z == 0) return V3s(0.f);
-    bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
-    v3 f = V3s(0.f);
-    for (int i = 0; i < b.n; i++)
-        if (lobe_matches(b.lobes[i], skipSpecular) && reflect) f = f + lobe_f(m, b.lobes[i], wo, wi);
-    return f;
-}
-// BSDF::Pdf reflection.h:174-188
-__device__ __forceinline__ float bsdf_pdf(const Bsdf& b, const DevMaterial& m, v3 woW, v3 wiW, bool skipSpecular) {
-    if (b.n == 0) return 0.f;
-    v3 wo = w2l(b, woW), wi = w2l(b, wiW);
-    if (wo.z == 0) return 0.f;
-    float pdf = 0.f;
-    int matching = 0;
-    for (int i = 0; i < b.n; i++)
-        if (lobe_matches(b.lobes[i], skipSpecular)) {
-            ++matching;
-            pdf += lobe_pdf(m, b.lobes[i], wo, wi);
-        }
-    return matching > 0 ? pdf / matching : 0.f;
-}
-// BSDF::Sample_f reflection.h:124-172.  pdf_io: on entry the caller's variable (left untouched on the wo.z==0 early
-// out, quirk 9)
+// BSDF::Sample_f reflection.h:124-172.  pdf_io: the caller's variable (left untouched on the wo.z==0 early out, quirk 9)
 __device__ __forceinline__ v3 bsdf_sample_f(const Bsdf& b, const DevMaterial& m, v3 woW, v3* wiW, float u0, float u1,
                                             float* pdf_io, bool skipSpecular, bool* sampledSpecular) {
-    int matching = 0;
-    for (int i = 0; i < b.n; i++)
-        if (lobe_matches(b.lobes[i], skipSpecular)) matching++;
+    uint32_t mask = lobes_matching(b, skipSpecular);
+    int matching = __popc(mask);
     if (matching == 0) {
         *pdf_io = 0;
         return V3s(0.f);
     }
     int comp = (int)floorf(u0 * matching);
     if (matching - 1 < comp) comp = matching - 1;
-    int lobe = -1, slot = -1, count = comp;
-    for (int i = 0; i < b.n; i++)
-        if (lobe_matches(b.lobes[i], skipSpecular) && count-- == 0) {
-            lobe = b.lobes[i];
-            slot = i;
-            break;
-        }
+    // the comp-th matching lobe in list order
+    uint32_t mm = mask;
+    for (int i = 0; i < comp; ++i) mm &= mm - 1;
+    int lobe = __ffs((int)mm) - 1;
     float ur0 = sminf(u0 * matching - comp, AGPT_ONE_MINUS_EPS);
     v3 wi = V3s(0.f), wo = w2l(b, woW);
     if (wo.z == 0) return V3s(0.f);
     *pdf_io = 0;
     if (sampledSpecular) *sampledSpecular = (lobe == LOBE_SPECULAR);
-    v3 f = lobe_sample_f(m, lobe, wo, &wi, ur0, u1, pdf_io);
+    v3 f = lobe_sample(m, lobe, wo, &wi, ur0, u1, pdf_io);
     if (*pdf_io == 0) return V3s(0.f);
     *wiW = l2w(b, wi);
-    if (lobe != LOBE_SPECULAR && matching > 1)
-        for (int i = 0; i < b.n; i++)
-            if (i != slot && lobe_matches(b.lobes[i], skipSpecular)) *pdf_io += lobe_pdf(m, b.lobes[i], wo, wi);
-    if (matching > 1) *pdf_io /= matching;
-    if (lobe != LOBE_SPECULAR) {
-        bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
-        f = V3s(0.f);
-        for (int i = 0; i < b.n; i++)
-            if (lobe_matches(b.lobes[i], skipSpecular) && reflect) f = f + lobe_f(m, b.lobes[i], wo, wi);
+    if (lobe == LOBE_SPECULAR) {
+        if (matching > 1) *pdf_io /= matching;
+        return f;
     }
-    return f;
+    bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
+    // *pdf += other lobes' Pdf (in list order), f = sum of all matching lobes' f if reflect
+    LobeEval e = bsdf_eval_lobes(&m, mask, wo, wi, matching > 1 ? lobe : -2, *pdf_io, reflect);
+    if (matching > 1) *pdf_io = e.pdf / matching;
+    return reflect ? e.f : V3s(0.f);
 }
 
 // ---- SurfaceInteraction reconstruction ----------------------------------------------------------------------

@@ -68,9 +68,29 @@ __device__ __forceinline__ bool box_test_t(float bx0, float by0, float bz0, floa
     dist = tmin;
     return ok;
 }
+
+// Fast-path slab test (all |D| >= 2^-40: every quotient is a finite non-NaN number).  Equivalent to the reference's
+// per-axis chain (bvhtrimesh.h:22-33) because
+//   * with no NaNs the comparator min/max (a<b?a:b) and the hardware v_min/v_max agree up to the sign of zero,
+//     which no later comparison can observe;
+//   * tmin_k is non-decreasing and tmax_k non-increasing over the axes and x -> x*1.00000024f is monotone, so
+//     "some prefix has tmax_k*c < tmin_k" holds iff it holds after the last axis: one reject test instead of three.
+// 6 sub + 18 (Markstein divides) + 6 min/max + 2 max3/min3-class + 2 clamp + 2 = 36 VALU ops per box (was 57).
+__device__ __forceinline__ bool box_test_fast(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
+                                              const TraceRay& r, float rayt, float& dist) {
+    float q0x = mdiv(bx0 - r.O.x, r.D.x, r.R.x), q1x = mdiv(bx1 - r.O.x, r.D.x, r.R.x);
+    float q0y = mdiv(by0 - r.O.y, r.D.y, r.R.y), q1y = mdiv(by1 - r.O.y, r.D.y, r.R.y);
+    float q0z = mdiv(bz0 - r.O.z, r.D.z, r.R.z), q1z = mdiv(bz1 - r.O.z, r.D.z, r.R.z);
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(q0x, q1x), __builtin_fminf(q0y, q1y)),
+                                 __builtin_fmaxf(__builtin_fminf(q0z, q1z), 0.0f));
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(q0x, q1x), __builtin_fmaxf(q0y, q1y)),
+                                 __builtin_fminf(__builtin_fmaxf(q0z, q1z), rayt));
+    dist = tmin;
+    return !((tmax * 1.00000024f) < tmin);
+}
 __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
                                          const TraceRay& r, float rayt, float& dist) {
-    if (__builtin_expect(r.fast, 1)) return box_test_t<true>(bx0, by0, bz0, bx1, by1, bz1, r, rayt, dist);
+    if (__builtin_expect(r.fast, 1)) return box_test_fast(bx0, by0, bz0, bx1, by1, bz1, r, rayt, dist);
     return box_test_t<false>(bx0, by0, bz0, bx1, by1, bz1, r, rayt, dist);
 }
 
@@ -98,10 +118,10 @@ __device__ __forceinline__ bool tri_test(v3 v0, v3 v1, v3 v2, const TraceRay& r,
 }
 
 // intersectable.h:164-181 / :207-226: nearest root in [0, rayt]
-__device__ __forceinline__ bool sphere_test(const DevPrim& P, const TraceRay& r, float rayt, float& root_out) {
-    v3 oc = r.O - V3(P.cx, P.cy, P.cz);
+__device__ __forceinline__ bool sphere_test_c(v3 center, float r2, const TraceRay& r, float rayt, float& root_out) {
+    v3 oc = r.O - center;
     float half_b = dot(oc, r.D);
-    float c = sqrlen(oc) - P.r2;
+    float c = sqrlen(oc) - r2;
     float discriminant = half_b * half_b - c;
     if (discriminant < 0) return false;
     float sqrtd = sqrtf(discriminant);
@@ -112,6 +132,9 @@ __device__ __forceinline__ bool sphere_test(const DevPrim& P, const TraceRay& r,
     }
     root_out = root;
     return true;
+}
+__device__ __forceinline__ bool sphere_test(const DevPrim& P, const TraceRay& r, float rayt, float& root_out) {
+    return sphere_test_c(V3(P.cx, P.cy, P.cz), P.r2, r, rayt, root_out);
 }
 
 __device__ __forceinline__ uint32_t encode_child(uint32_t node_index, uint32_t first, uint32_t count) {
