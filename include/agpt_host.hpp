@@ -1,0 +1,223 @@
+// include/agpt_host.hpp -- C++ host adapter over the C ABI of include/agpt.h.
+//
+// Header-only mirror of the reference's host-side surface for the path-tracing hot path, so that code written
+// like MyApp::Init / MyApp::Tick (myapp.cpp:13-135,141-190) keeps its shape while the per-pixel loop, BVH traversal
+// and shading run on the MI355X:
+//
+//   reference (paths relative to the reference checkout)            this header
+//   ---------------------------------------------------------------------------------------------------------
+//   DisneyMaterial::Make(color, rough, metallic)  material.h:60     agpt::DisneyMaterial::Make(scene, ...)
+//   MirrorMaterial::Make(r)                        material.h:83     agpt::MirrorMaterial::Make(scene, r)
+//   TriangleMesh::CreateBackdrop(...)              trianglemesh.cpp:232   agpt::TriangleMesh::CreateBackdrop(...)
+//   make_shared<BVHTriMesh>(mesh, mat, 1)          bvhtrimesh.h:154  scene.primitives_push_back(mesh, mat, 1)
+//   make_shared<Sphere>(c, r, mat)                 intersectable.h:161    scene.primitives_push_back(Sphere{c, r}, mat)
+//   scene->addAreaLight(sphere, L)                 scene.h:21        scene.addAreaLight(Sphere{c, r}, L)
+//   scene->lights.push_back(UniformInfiniteLight)  lights.h:37       scene.lights_push_back(UniformInfiniteLight{L})
+//   scene->camera = CameraDesc{...}                camera.h:17       scene.camera = ...; (applied at commit)
+//   Scene::Intersect / IntersectP                  scene.h:5-19      scene.Intersect(rays, n, hits) / IntersectP
+//   PathTracer(maxDepth).Li per pixel + Accumulator::AddSample       agpt::PathTracer(maxDepth).Render(scene, accum, spp)
+//   Accumulator (sum buffer, y flip, sample count) myapp.h:8-68      agpt::Accumulator
+//
+// Errors: the reference has no error returns (bool hit/miss, exit() on load failure); here every failing C call
+// throws agpt::Error carrying agpt_last_error().
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "agpt.h"
+
+namespace agpt {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what + ": " + agpt_last_error()), code(c) {}
+};
+inline int check(int rc, const char* what) {
+    if (rc < 0) throw Error(rc, what);
+    return rc;
+}
+
+struct float3 {
+    float x, y, z;
+};
+
+class Context {
+public:
+    explicit Context(int device = 0, void* hip_stream = nullptr) {
+        check(agpt_init(device, &h_), "agpt_init");
+        if (hip_stream) check(agpt_set_stream(h_, hip_stream), "agpt_set_stream");
+    }
+    ~Context() { agpt_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    agpt_ctx* handle() const { return h_; }
+
+private:
+    agpt_ctx* h_ = nullptr;
+};
+
+// TriangleMesh (trianglemesh.h:14-57): AoS arrays + (v, n, t) index triplets
+struct TriangleMesh {
+    std::vector<float> vertices, normals, texcoords;
+    std::vector<int32_t> indices;
+
+    static TriangleMesh CreateBackdrop(float3 origin, float3 size, float radius, int steps) {
+        TriangleMesh m;
+        const int nv = 2 * (steps + 5), ni = 6 * (steps + 4);
+        m.vertices.resize(3 * nv);
+        m.normals.resize(3 * nv);
+        m.texcoords.resize(2 * nv);
+        m.indices.resize(3 * ni);
+        const float o[3] = {origin.x, origin.y, origin.z}, s[3] = {size.x, size.y, size.z};
+        int n_v = 0, n_i = 0;
+        check(agpt_create_backdrop(o, s, radius, steps, m.vertices.data(), m.normals.data(), m.texcoords.data(),
+                                   m.indices.data(), &n_v, &n_i),
+              "agpt_create_backdrop");
+        return m;
+    }
+};
+
+struct Sphere {
+    float3 center;
+    float radius;
+};
+struct UniformInfiniteLight {
+    float3 L;
+};
+using CameraDesc = agpt_camera_desc;
+
+class Scene {
+public:
+    explicit Scene(Context& ctx) : ctx_(ctx) {
+        check(agpt_scene_create(ctx.handle(), &h_), "agpt_scene_create");
+        camera = CameraDesc{{0, 0, 1}, {0, 0, 0}, {0, 1, 0}, 1.f, 45.f, 0.f};
+    }
+    ~Scene() { agpt_scene_destroy(h_); }
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+
+    int add_material(int type, float3 color, float roughness, float metallic) {
+        const float c[3] = {color.x, color.y, color.z};
+        return check(agpt_scene_add_material(h_, type, c, roughness, metallic), "agpt_scene_add_material");
+    }
+    // scene->primitives.push_back(make_shared<BVHTriMesh>(mesh, material, maxPrimsInNode))
+    int primitives_push_back(const TriangleMesh& m, int material, int maxPrimsInNode = 1) {
+        return check(agpt_scene_add_mesh(h_, m.vertices.data(), (int)m.vertices.size() / 3, m.normals.data(),
+                                         (int)m.normals.size() / 3, m.texcoords.data(), (int)m.texcoords.size() / 2,
+                                         m.indices.data(), (int)m.indices.size() / 3, material, maxPrimsInNode),
+                     "agpt_scene_add_mesh");
+    }
+    // scene->primitives.push_back(make_shared<Sphere>(center, radius, material)); material -1 = nullptr
+    int primitives_push_back(const Sphere& s, int material) {
+        const float c[3] = {s.center.x, s.center.y, s.center.z};
+        return check(agpt_scene_add_sphere(h_, c, s.radius, material), "agpt_scene_add_sphere");
+    }
+    int addAreaLight(const Sphere& s, float3 L) {
+        const float c[3] = {s.center.x, s.center.y, s.center.z}, l[3] = {L.x, L.y, L.z};
+        return check(agpt_scene_add_area_light(h_, c, s.radius, l), "agpt_scene_add_area_light");
+    }
+    int lights_push_back(const UniformInfiniteLight& l) {
+        const float c[3] = {l.L.x, l.L.y, l.L.z};
+        return check(agpt_scene_add_uniform_infinite_light(h_, c), "agpt_scene_add_uniform_infinite_light");
+    }
+    // upload to HBM; call once after the scene is built (and again after changing `camera`)
+    void commit() {
+        check(agpt_scene_set_camera(h_, &camera), "agpt_scene_set_camera");
+        check(agpt_scene_commit(h_), "agpt_scene_commit");
+    }
+    void Intersect(const agpt_ray* rays, int n, agpt_hit* hits) const {
+        check(agpt_intersect_batch(h_, rays, n, hits, 0, nullptr), "agpt_intersect_batch");
+    }
+    void IntersectP(const agpt_ray* rays, int n, agpt_hit* hits) const {
+        check(agpt_intersect_batch(h_, rays, n, hits, 1, nullptr), "agpt_intersect_batch");
+    }
+    // single-ray convenience for picking / debugging (myapp.cpp:200-201)
+    bool Intersect(const agpt_ray& ray, agpt_hit& hit) const {
+        Intersect(&ray, 1, &hit);
+        return hit.hit != 0;
+    }
+
+    CameraDesc camera;
+    agpt_scene* handle() const { return h_; }
+    Context& context() const { return ctx_; }
+
+private:
+    Context& ctx_;
+    agpt_scene* h_ = nullptr;
+};
+
+struct DisneyMaterial {
+    static int Make(Scene& s, float3 color, float roughness, float metallic) {
+        return s.add_material(AGPT_MAT_DISNEY, color, roughness, metallic);
+    }
+};
+struct MirrorMaterial {
+    static int Make(Scene& s, float3 r) { return s.add_material(AGPT_MAT_MIRROR, r, 0.f, 0.f); }
+};
+
+// Accumulator (myapp.h:8-68): float sum buffer in HBM (float4 per pixel, row H-1-y), sample count, clear, resolve
+class Accumulator {
+public:
+    Accumulator(Context& ctx, int w, int h) : width(w), height(h), ctx_(ctx) {
+        check(agpt_device_alloc(ctx.handle(), (size_t)w * h * 16, &pixels_), "agpt_device_alloc");
+        Clear();
+    }
+    ~Accumulator() { agpt_device_free(ctx_.handle(), pixels_); }
+    Accumulator(const Accumulator&) = delete;
+    Accumulator& operator=(const Accumulator&) = delete;
+    void Clear() {
+        check(agpt_device_memset(ctx_.handle(), pixels_, 0, (size_t)width * height * 16), "agpt_device_memset");
+        samples_ = 0;
+    }
+    int NumSamples() const { return samples_; }
+    void AddSamples(int n) { samples_ += n; }
+    float* device_pixels() const { return static_cast<float*>(pixels_); }
+    // CopyToSurface: gamma 2.2 + 0x00RRGGBB (myapp.h:34-41)
+    std::vector<uint32_t> CopyToSurface() const {
+        std::vector<uint32_t> out((size_t)width * height);
+        check(agpt_resolve(ctx_.handle(), device_pixels(), width * height, samples_, out.data()), "agpt_resolve");
+        return out;
+    }
+    std::vector<float> Download() const {
+        std::vector<float> out((size_t)width * height * 4);
+        check(agpt_device_download(ctx_.handle(), out.data(), pixels_, out.size() * 4), "agpt_device_download");
+        return out;
+    }
+    const int width, height;
+
+private:
+    Context& ctx_;
+    void* pixels_ = nullptr;
+    int samples_ = 0;
+};
+
+// Integrator / PathTracer (integrator.h:28-31,120-196).  Li is evaluated for whole frames: one Render() call is
+// `spp` iterations of MyApp::Tick's per-pixel loop (myapp.cpp:161-175).
+class PathTracer {
+public:
+    explicit PathTracer(int maxDepth = 5) : MaxDepth(maxDepth) {}
+    agpt_stats Render(Scene& scene, Accumulator& acc, int spp, uint32_t seed_base = 0) const {
+        agpt_render_params p{};
+        p.width = acc.width;
+        p.height = acc.height;
+        p.x0 = 0;
+        p.y0 = 0;
+        p.w = acc.width;
+        p.h = acc.height;
+        p.spp_begin = acc.NumSamples();
+        p.spp_count = spp;
+        p.seed_base = seed_base;
+        p.max_depth = MaxDepth;
+        p.accum_pitch = acc.width;
+        agpt_stats st{};
+        check(agpt_render(scene.handle(), &p, acc.device_pixels(), &st), "agpt_render");
+        acc.AddSamples(spp);
+        return st;
+    }
+    int MaxDepth;
+};
+
+}  // namespace agpt
