@@ -69,6 +69,7 @@ struct agpt_ctx {
     uint32_t* host_pinned = nullptr;
     int blocks_per_cu = 4;       // AGPT_BLOCKS_PER_CU
     int refill = AGPT_REFILL;    // AGPT_REFILL: idle lanes that trigger an in-flight refill
+    int vote[3] = {1, 1, 1};     // AGPT_VOTE=a,b,c: phase weights of the trace kernel's vote scheduler (tuning)
     bool force_generic = false;  // AGPT_FORCE_GENERIC=1: always use the generic k_trace (tests)
     // per-launch HIP-event timing of the trace kernels (agpt_render_params::enable_timing)
     std::vector<hipEvent_t> tev;
@@ -110,7 +111,7 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
     if (!count && sc.n_prims <= 64 && !c->force_generic)
         hipLaunchKernelGGL((k_trace_fast<ANY>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
-                           hits, occ, c->counters.p, c->refill);
+                           hits, occ, c->counters.p, c->refill, c->vote[0], c->vote[1], c->vote[2]);
     else if (count)
         hipLaunchKernelGGL((k_trace<ANY, true>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
                            hits, occ, c->counters.p);
@@ -164,6 +165,7 @@ int agpt_init(int device, agpt_ctx** out) {
     c->force_generic = fg && fg[0] == '1';
     if (const char* bp = getenv("AGPT_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(bp));
     if (const char* rf = getenv("AGPT_REFILL")) c->refill = std::min(64, std::max(1, atoi(rf)));
+    if (const char* vt = getenv("AGPT_VOTE")) sscanf(vt, "%d:%d:%d", &c->vote[0], &c->vote[1], &c->vote[2]);
     *out = c.release();
     return AGPT_OK;
 }

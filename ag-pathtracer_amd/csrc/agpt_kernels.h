@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(AGPT_BLOCK)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
              DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters,
-             int refill) {
+             int refill, int vote_a, int vote_b, int vote_c) {
     __shared__ uint32_t s_stack[AGPT_STACK_DEPTH * AGPT_BLOCK];
     __shared__ float4 s_prim[2 * 64];
     uint32_t* stack = s_stack + threadIdx.x;
@@ -240,10 +240,82 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         }
         if (act == 0) break;
 
-        // ---- traversal round --------------------------------------------------------------------------------
+        // ---- traversal round: vote scheduling -------------------------------------------------------------------
+        // Each lane is in one of three states: A = between meshes (pick the next primitive of its mask), B = at an
+        // interior node, C = at a leaf.  Every step the wave executes the body most lanes are waiting for (weighted by
+        // body cost); a lane's own sequence of operations is the reference's, only the interleaving between lanes
+        // changes.  (A while-while loop makes every lane wait for the longest descent in the wave: 37 % active lanes.)
         for (;;) {
-            // A: lanes between meshes pick their next primitive (list order) or retire
-            while (active && !in_mesh) {
+            const bool wantA = active && !in_mesh;
+            const bool wantB = active && in_mesh && !(cur & AGPT_ENC_LEAF);
+            const bool wantC = active && in_mesh && (cur & AGPT_ENC_LEAF);
+            const int nA = __popcll(__ballot(wantA)), nB = __popcll(__ballot(wantB)), nC = __popcll(__ballot(wantC));
+            if (nB * vote_b >= nA * vote_a && nB * vote_b >= nC * vote_c) {
+                if (wantB) {
+                    const float4* np = sc.nodes + 2 * (size_t)cur;
+                    float4 a0 = np[0], a1 = np[1], b0 = np[2], b1 = np[3];
+                    float dl, dr;
+                    bool hl = box_test(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
+                    bool hr = box_test(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
+                    uint32_t encl = encode_child(cur, __float_as_uint(a1.z), __float_as_uint(a1.w));
+                    uint32_t encr = encode_child(cur + 1, __float_as_uint(b1.z), __float_as_uint(b1.w));
+                    if (hl && hr) {
+                        bool swap = ANY ? false : (dr < dl);
+                        stack[sp * AGPT_BLOCK] = swap ? encl : encr;
+                        sp++;
+                        cur = swap ? encr : encl;
+                    } else if (hl) {
+                        cur = encl;
+                    } else if (hr) {
+                        cur = encr;
+                    } else if (sp == 0) {
+                        in_mesh = false;
+                    } else {
+                        sp--;
+                        cur = stack[sp * AGPT_BLOCK];
+                    }
+                }
+            } else if (nC * vote_c >= nA * vote_a) {
+                if (wantC) {
+                    uint32_t first, cnt;
+                    if ((cur & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
+                        float4 n1 = sc.nodes[2 * (size_t)(cur & 0x0FFFFFFFu) + 1];
+                        first = __float_as_uint(n1.z);
+                        cnt = __float_as_uint(n1.w);
+                    } else {
+                        first = cur & 0x0FFFFFFFu;
+                        cnt = ((cur >> 28) & 7u) + 1u;
+                    }
+                    bool done = false;
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
+                        float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                        float t, b1, b2;
+                        if (tri_test(V3(q0.x, q0.y, q0.z), V3(q1.x, q1.y, q1.z), V3(q2.x, q2.y, q2.z), r, rayt, t, b1, b2)) {
+                            if (ANY) {
+                                done = true;
+                                break;
+                            }
+                            if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
+                                rayt = t;
+                                hid = __float_as_uint(q0.w);
+                                hb1 = b1;
+                                hb2 = b2;
+                            }
+                        }
+                    }
+                    if (ANY && done) {
+                        occluded[pid] = 1u;
+                        active = false;
+                    } else if (sp == 0) {
+                        in_mesh = false;
+                    } else {
+                        sp--;
+                        cur = stack[sp * AGPT_BLOCK];
+                    }
+                }
+            } else if (wantA) {
+                // next primitive of this lane's mask (list order), or retire
                 if (mask == 0) {
                     if (ANY)
                         occluded[pid] = 0u;
@@ -256,95 +328,31 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         hits[pid] = h;
                     }
                     active = false;
-                    break;
-                }
-                const int k = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
-                if (pa.w == 1.f) {
-                    float root;
-                    if (sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, r, rayt, root)) {
-                        if (ANY) {
-                            occluded[pid] = 1u;
-                            active = false;
-                            break;
-                        }
-                        rayt = root;
-                        hid = AGPT_HIT_SPHERE | (uint32_t)k;
-                        hb1 = 0.f;
-                        hb2 = 0.f;
-                    }
-                    continue;
-                }
-                if (pa.w != 0.f) continue;
-                float dist;
-                if (!box_test(pa.x, pa.y, pa.z, pb2.x, pb2.y, pb2.z, r, rayt, dist)) continue;
-                cur = __float_as_uint(pb2.w);
-                sp = 0;
-                in_mesh = true;
-            }
-            // B: descend interior nodes until a leaf (or the mesh is exhausted)
-            while (active && in_mesh && !(cur & AGPT_ENC_LEAF)) {
-                const float4* np = sc.nodes + 2 * (size_t)cur;
-                float4 a0 = np[0], a1 = np[1], b0 = np[2], b1 = np[3];
-                float dl, dr;
-                bool hl = box_test(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
-                bool hr = box_test(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
-                uint32_t encl = encode_child(cur, __float_as_uint(a1.z), __float_as_uint(a1.w));
-                uint32_t encr = encode_child(cur + 1, __float_as_uint(b1.z), __float_as_uint(b1.w));
-                if (hl && hr) {
-                    bool swap = ANY ? false : (dr < dl);
-                    stack[sp * AGPT_BLOCK] = swap ? encl : encr;
-                    sp++;
-                    cur = swap ? encr : encl;
-                } else if (hl) {
-                    cur = encl;
-                } else if (hr) {
-                    cur = encr;
-                } else if (sp == 0) {
-                    in_mesh = false;
                 } else {
-                    sp--;
-                    cur = stack[sp * AGPT_BLOCK];
-                }
-            }
-            // C: leaf
-            if (active && in_mesh) {
-                uint32_t first, cnt;
-                if ((cur & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
-                    float4 n1 = sc.nodes[2 * (size_t)(cur & 0x0FFFFFFFu) + 1];
-                    first = __float_as_uint(n1.z);
-                    cnt = __float_as_uint(n1.w);
-                } else {
-                    first = cur & 0x0FFFFFFFu;
-                    cnt = ((cur >> 28) & 7u) + 1u;
-                }
-                bool done = false;
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
-                    float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                    float t, b1, b2;
-                    if (tri_test(V3(q0.x, q0.y, q0.z), V3(q1.x, q1.y, q1.z), V3(q2.x, q2.y, q2.z), r, rayt, t, b1, b2)) {
-                        if (ANY) {
-                            done = true;
-                            break;
+                    const int k = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
+                    if (pa.w == 1.f) {
+                        float root;
+                        if (sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, r, rayt, root)) {
+                            if (ANY) {
+                                occluded[pid] = 1u;
+                                active = false;
+                            } else {
+                                rayt = root;
+                                hid = AGPT_HIT_SPHERE | (uint32_t)k;
+                                hb1 = 0.f;
+                                hb2 = 0.f;
+                            }
                         }
-                        if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
-                            rayt = t;
-                            hid = __float_as_uint(q0.w);
-                            hb1 = b1;
-                            hb2 = b2;
+                    } else if (pa.w == 0.f) {
+                        float dist;
+                        if (box_test(pa.x, pa.y, pa.z, pb2.x, pb2.y, pb2.z, r, rayt, dist)) {
+                            cur = __float_as_uint(pb2.w);
+                            sp = 0;
+                            in_mesh = true;
                         }
                     }
-                }
-                if (ANY && done) {
-                    occluded[pid] = 1u;
-                    active = false;
-                } else if (sp == 0) {
-                    in_mesh = false;
-                } else {
-                    sp--;
-                    cur = stack[sp * AGPT_BLOCK];
                 }
             }
             act = __ballot(active);
