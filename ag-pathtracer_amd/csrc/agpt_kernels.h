@@ -136,7 +136,8 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 //     processed once all lanes have reached one, then lanes whose mesh is finished pick their next primitive;
 //   * the wave-uniform phase-A filter uses the cheap slab test (b-O)*RN(1/D) with a widened reject margin, which
 //     can only over-accept; the exact Bounds::Intersect is re-run per lane where the reference runs it.
-#define AGPT_REFILL 32
+#define AGPT_REFILL 20
+#define AGPT_RING 128  // entries of the per-wave ring of pre-filtered rays (power of two, >= 64 + 63)
 // per-primitive root record staged in LDS: [2k] = (bmin.xyz | sphere centre.xyz, kind), [2k+1] = (bmax.xyz, root_enc) |
 // (r2, -, -, -); kind 0 = mesh, 1 = sphere, 2 = empty mesh (never hit)
 
@@ -187,21 +188,67 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     r.R = V3s(1.f);
     r.fast = true;
 
+    // wave-private ring of pre-filtered rays (path id + primitive mask), filled 64 rays at a time
+    __shared__ uint32_t s_ring_pid[AGPT_BLOCK / 64][AGPT_RING];
+    __shared__ unsigned long long s_ring_mask[AGPT_BLOCK / 64][AGPT_RING];
+    uint32_t* ring_pid = s_ring_pid[threadIdx.x >> 6];
+    unsigned long long* ring_mask = s_ring_mask[threadIdx.x >> 6];
+    uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, monotonically increasing
+
     for (;;) {
         // ---- refill ---------------------------------------------------------------------------------------
         unsigned long long act = __ballot(active);
         int n_active = __popcll(act);
-        if (!exhausted && n_active <= 64 - refill) {
-            const int n_idle = 64 - n_active;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(work_head, (uint32_t)n_idle);
-            base = __shfl(base, 0);
-            if (base + (uint32_t)n_idle >= count) exhausted = true;
-            bool fresh = false;
+        if (n_active <= 64 - refill && !(exhausted && ring_head == ring_tail)) {
+            const uint32_t n_idle = (uint32_t)(64 - n_active);
+            // top the ring up from the single global queue frontier: phase A runs for 64 NEW rays with all lanes busy
+            while (ring_tail - ring_head < n_idle && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_head, 64u);
+                base = __shfl(base, 0);
+                if (base + 64u >= count) exhausted = true;
+                const uint32_t n_new = base < count ? (count - base < 64u ? count - base : 64u) : 0u;
+                if ((uint32_t)lane < n_new) {
+                    const uint32_t npid = queue ? queue[base + lane] : base + lane;
+                    const float4 o = ray_o[npid], d = ray_d[npid];
+                    const TraceRay nr = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
+                    // phase A: conservative per-primitive filter at the initial t
+                    unsigned long long m = 0;
+                    for (int k = 0; k < n_prims; ++k) {
+                        const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
+                        bool h;
+                        if (pa.w == 1.f) {
+                            float root;
+                            h = sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, nr, o.w, root);
+                        } else {
+                            float t0x = (pa.x - nr.O.x) * nr.R.x, t1x = (pb2.x - nr.O.x) * nr.R.x;
+                            float t0y = (pa.y - nr.O.y) * nr.R.y, t1y = (pb2.y - nr.O.y) * nr.R.y;
+                            float t0z = (pa.z - nr.O.z) * nr.R.z, t1z = (pb2.z - nr.O.z) * nr.R.z;
+                            float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
+                            float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), o.w));
+                            // exact test rejects iff tmax*1.00000024 < tmin; products are within 2 ulp of the quotients
+                            h = pa.w == 0.f && !(tmax * 1.000002f < tmin);
+                        }
+                        m |= (unsigned long long)(h ? 1u : 0u) << k;
+                    }
+                    const uint32_t slot = (ring_tail + (uint32_t)lane) & (AGPT_RING - 1);
+                    ring_pid[slot] = npid;
+                    ring_mask[slot] = nr.fast ? m : all_prims;
+                }
+                ring_tail += n_new;
+            }
+            // hand ring entries to idle lanes (same wave wrote them: a wave barrier orders the LDS writes and reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t avail = ring_tail - ring_head;
+            const uint32_t take = n_idle < avail ? n_idle : avail;
             if (!active) {
-                uint32_t i = base + (uint32_t)__popcll(~act & lt_mask);
-                if (i < count) {
-                    pid = queue ? queue[i] : i;
+                const uint32_t rank = (uint32_t)__popcll(~act & lt_mask);
+                if (rank < take) {
+                    const uint32_t slot = (ring_head + rank) & (AGPT_RING - 1);
+                    pid = ring_pid[slot];
+                    mask = ring_mask[slot];
                     float4 o = ray_o[pid], d = ray_d[pid];
                     r = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                     rayt = o.w;
@@ -210,32 +257,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     hb2 = 0.f;
                     in_mesh = false;
                     sp = 0;
-                    fresh = true;
                     active = true;
                 }
             }
-            if (__ballot(fresh)) {
-                // phase A: conservative per-primitive filter at the initial t (wave-uniform loop)
-                unsigned long long m = 0;
-                for (int k = 0; k < n_prims; ++k) {
-                    const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
-                    bool h;
-                    if (pa.w == 1.f) {
-                        float root;
-                        h = sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, r, rayt, root);
-                    } else {
-                        float t0x = (pa.x - r.O.x) * r.R.x, t1x = (pb2.x - r.O.x) * r.R.x;
-                        float t0y = (pa.y - r.O.y) * r.R.y, t1y = (pb2.y - r.O.y) * r.R.y;
-                        float t0z = (pa.z - r.O.z) * r.R.z, t1z = (pb2.z - r.O.z) * r.R.z;
-                        float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
-                        float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), rayt));
-                        // exact test rejects iff tmax*1.00000024 < tmin; products are within 2 ulp of the quotients
-                        h = pa.w == 0.f && !(tmax * 1.000002f < tmin);
-                    }
-                    m |= (unsigned long long)(h ? 1u : 0u) << k;
-                }
-                if (fresh) mask = r.fast ? m : all_prims;
-            }
+            ring_head += take;
             act = __ballot(active);
         }
         if (act == 0) break;
@@ -357,7 +382,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             }
             act = __ballot(active);
             if (act == 0) break;
-            if (!exhausted && __popcll(act) <= 64 - refill) break;
+            if (__popcll(act) <= 64 - refill && !(exhausted && ring_head == ring_tail)) break;
         }
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
