@@ -1,0 +1,94 @@
+"""BASELINE.json's full-size configurations on the GPU.  The oracle cannot render 1080p/64spp in test time, so at full
+size parity is carried by (a) oracle comparison on a small tile of the full film and scene (the RNG streams are global
+per (pixel, sample), so a tile of the big render is exactly what the oracle computes for that tile), and
+(b) size-independent properties: tile-split, sample-split and rank-split invariance (all bit-exact), determinism."""
+import numpy as np
+import pytest
+
+import ag_pathtracer_amd as ag
+from ag_pathtracer_amd import tiles
+from helpers import gpu_scene, oracle_scene
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_tile(desc, W, H, spp, tile):
+    o = oracle_scene(desc)
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        return o.render(W, H, spp, tile=tile, threads=8)
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+
+
+def tile_rows(acc, H, tile):
+    x0, y0, w, h = tile
+    return acc[H - y0 - h:H - y0, x0:x0 + w, :3]
+
+
+def test_c3_full_scene_1080p_tile_vs_oracle_and_invariances():
+    W, H, spp = 1920, 1080, 2
+    desc = ag.scenes.scene_c3()
+    assert 254000 <= desc.n_tris <= 266000 and desc.n_prims == 37
+    g = gpu_scene(desc)
+    pt = ag.PathTracer(5)
+    full, st = pt.render_to_host(g, W, H, spp)
+    assert st.samples == W * H * spp and st.outliers == 0
+    # (a) a 96x54 tile of the full film against the oracle
+    tile = (912, 500, 96, 54)
+    oacc, ost = oracle_tile(desc, W, H, spp, tile)
+    a, b = tile_rows(full, H, tile), tile_rows(oacc, H, tile)
+    assert np.mean(np.all(a.view(np.uint32) == b.view(np.uint32), axis=-1)) >= 0.999
+    # (b1) determinism
+    again, st2 = pt.render_to_host(g, W, H, spp)
+    assert again.tobytes() == full.tobytes() and st2.rays == st.rays
+    # (b2) sample split: 1 spp + 1 spp accumulated progressively == 2 spp; small batches == large batches
+    ctx = g.ctx
+    ptr = ctx.alloc(W * H * 16)
+    ctx.memset(ptr, 0, W * H * 16)
+    pt.render(g, W, H, 1, ptr, spp_begin=0)
+    pt.render(g, W, H, 1, ptr, spp_begin=1, samples_per_batch=1)
+    split = ctx.download(ptr, (H, W, 4))
+    assert split.tobytes() == full.tobytes()
+    # (b3) tile split == rank split: the 8-row-block interleave of a 3-rank run, gathered, equals the full render
+    world = 3
+    bufs = []
+    for r in range(world):
+        rows = tiles.max_local_rows(H, world)
+        ctx.memset(ptr, 0, W * H * 16)
+        for (y0, h, off) in tiles.row_blocks(H, r, world):
+            pt.render(g, W, H, spp, ptr, tile=(0, y0, W, h), accum_row0=tiles.block_accum_row0(H, y0, h, off), want_stats=False)
+        bufs.append(ctx.download(ptr, (H, W, 4))[:rows].copy())
+    ctx.free(ptr)
+    assert tiles.deinterleave(bufs, W, H, world).tobytes() == full.tobytes()
+    g.close()
+
+
+def test_c2_full_size_tile_vs_oracle():
+    """BASELINE config 2: 70,010-triangle blob + backdrop, single DisneyDiffuse lobe, 1280x720 (16 spp in the config;
+    2 spp here), three sphere lights + sky."""
+    W, H, spp = 1280, 720, 2
+    desc = ag.scenes.scene_c2()
+    assert 69000 <= desc.n_tris <= 71000
+    g = gpu_scene(desc)
+    full, st = ag.PathTracer(5).render_to_host(g, W, H, spp)
+    g.close()
+    tile = (600, 330, 96, 54)
+    oacc, ost = oracle_tile(desc, W, H, spp, tile)
+    a, b = tile_rows(full, H, tile), tile_rows(oacc, H, tile)
+    assert np.mean(np.all(a.view(np.uint32) == b.view(np.uint32), axis=-1)) >= 0.999
+    assert st.outliers == 0
+
+
+def test_c5_class_all_metal_multi_mesh():
+    """BASELINE config 5's material class (all-metal GGX + MIS, many meshes) at reduced geometry size."""
+    W, H, spp = 192, 108, 2
+    desc = ag.scenes.scene_c3(scale=0.08, all_metal=True)
+    g = gpu_scene(desc)
+    acc, st = ag.PathTracer(5).render_to_host(g, W, H, spp)
+    g.close()
+    oacc, ost = oracle_tile(desc, W, H, spp, (0, 0, W, H))
+    same = np.all(acc[..., :3].view(np.uint32) == oacc[..., :3].view(np.uint32), axis=-1)
+    assert same.mean() >= 0.999
+    assert st.rays == ost.rays
