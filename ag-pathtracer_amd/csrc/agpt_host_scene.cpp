@@ -324,8 +324,17 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
             if (i == 1) continue;  // unused slot
             const agpt_bvh_node& n = mesh.nodes[i];
             uint32_t first = (uint32_t)n.first + (uint32_t)(n.count > 0 ? tb : nb);
+            // .z = the traversal encoding of this node (what a parent pushes / descends to), precomputed here so the
+            // kernels do not rebuild it per visit; big leaves keep first/count and are flagged in .w
+            uint32_t z = first, w = (uint32_t)n.count;
+            if (n.count > 0) {
+                if (n.count <= 7 && first < 0x10000000u)
+                    z = AGPT_ENC_LEAF | ((uint32_t)(n.count - 1) << 28) | first;
+                else
+                    w |= AGPT_NODE_BIGLEAF;
+            }
             out.nodes[2 * (nb + i)] = F4(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0]);
-            out.nodes[2 * (nb + i) + 1] = F4(n.bmax[1], n.bmax[2], bits(first), bits((uint32_t)n.count));
+            out.nodes[2 * (nb + i) + 1] = F4(n.bmax[1], n.bmax[2], bits(z), bits(w));
         }
         {
             const agpt_bvh_node& r = mesh.nodes[0];

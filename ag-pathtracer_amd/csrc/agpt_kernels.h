@@ -194,6 +194,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     uint32_t* ring_pid = s_ring_pid[threadIdx.x >> 6];
     unsigned long long* ring_mask = s_ring_mask[threadIdx.x >> 6];
     uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, monotonically increasing
+    bool any_slow = false;                  // wave-uniform: some active lane's ray needs the true-division slab test
 
     for (;;) {
         // ---- refill ---------------------------------------------------------------------------------------
@@ -212,7 +213,12 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     const uint32_t npid = queue ? queue[base + lane] : base + lane;
                     const float4 o = ray_o[npid], d = ray_d[npid];
                     const TraceRay nr = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
-                    // phase A: conservative per-primitive filter at the initial t
+                    // phase A: conservative per-primitive filter at the initial t.  t ~ fma(b, R, -RN(O*R)) differs from
+                    // the exact quotient (b-O)/D by at most 2^-23 |t| + 2^-24 |O*R| (R = RN(1/D), one rounding of O*R, one
+                    // of the fma); rejecting only when tmax*(1+2e-6) + 2E < tmin with E = 2^-22 max|O*R| can therefore
+                    // only over-accept -- the exact Bounds::Intersect still decides where the reference runs it.
+                    const float nox = -(nr.O.x * nr.R.x), noy = -(nr.O.y * nr.R.y), noz = -(nr.O.z * nr.R.z);
+                    const float slack2 = 0x1p-21f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
                     unsigned long long m = 0;
                     for (int k = 0; k < n_prims; ++k) {
                         const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
@@ -221,13 +227,12 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                             float root;
                             h = sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, nr, o.w, root);
                         } else {
-                            float t0x = (pa.x - nr.O.x) * nr.R.x, t1x = (pb2.x - nr.O.x) * nr.R.x;
-                            float t0y = (pa.y - nr.O.y) * nr.R.y, t1y = (pb2.y - nr.O.y) * nr.R.y;
-                            float t0z = (pa.z - nr.O.z) * nr.R.z, t1z = (pb2.z - nr.O.z) * nr.R.z;
+                            float t0x = __builtin_fmaf(pa.x, nr.R.x, nox), t1x = __builtin_fmaf(pb2.x, nr.R.x, nox);
+                            float t0y = __builtin_fmaf(pa.y, nr.R.y, noy), t1y = __builtin_fmaf(pb2.y, nr.R.y, noy);
+                            float t0z = __builtin_fmaf(pa.z, nr.R.z, noz), t1z = __builtin_fmaf(pb2.z, nr.R.z, noz);
                             float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
                             float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), o.w));
-                            // exact test rejects iff tmax*1.00000024 < tmin; products are within 2 ulp of the quotients
-                            h = pa.w == 0.f && !(tmax * 1.000002f < tmin);
+                            h = pa.w == 0.f && !(__builtin_fmaf(tmax, 1.000002f, slack2) < tmin);
                         }
                         m |= (unsigned long long)(h ? 1u : 0u) << k;
                     }
@@ -262,6 +267,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             }
             ring_head += take;
             act = __ballot(active);
+            any_slow = __ballot(active && !r.fast) != 0;
         }
         if (act == 0) break;
 
@@ -280,8 +286,14 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     const float4* np = sc.nodes + 2 * (size_t)cur;
                     float4 a0 = np[0], a1 = np[1], b0 = np[2], b1 = np[3];
                     float dl, dr;
-                    bool hl = box_test(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
-                    bool hr = box_test(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
+                    bool hl = box_test_fast(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
+                    bool hr = box_test_fast(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
+                    if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
+                        if (!r.fast) {
+                            hl = box_test_t<false>(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
+                            hr = box_test_t<false>(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
+                        }
+                    }
                     uint32_t encl = encode_child(cur, __float_as_uint(a1.z), __float_as_uint(a1.w));
                     uint32_t encr = encode_child(cur + 1, __float_as_uint(b1.z), __float_as_uint(b1.w));
                     if (hl && hr) {
@@ -306,7 +318,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     if ((cur & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
                         float4 n1 = sc.nodes[2 * (size_t)(cur & 0x0FFFFFFFu) + 1];
                         first = __float_as_uint(n1.z);
-                        cnt = __float_as_uint(n1.w);
+                        cnt = __float_as_uint(n1.w) & ~AGPT_NODE_BIGLEAF;
                     } else {
                         first = cur & 0x0FFFFFFFu;
                         cnt = ((cur >> 28) & 7u) + 1u;

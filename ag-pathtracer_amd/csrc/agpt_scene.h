@@ -1,7 +1,9 @@
 // agpt_scene.h -- flat, HBM-resident scene representation shared by the host builder and the kernels.
 //
 // Layout (all arrays 64-B aligned, replicated per GPU):
-//   nodes      float4[2*N]  reference BVHNode layout (bvhtrimesh.h:126-130): {bmin.xyz,bmax.x}{bmax.yz,first,count};
+//   nodes      float4[2*N]  reference BVHNode layout (bvhtrimesh.h:126-130): {bmin.xyz,bmax.x}{bmax.yz,first,count}, with
+//                           `first` replaced by the node's precomputed traversal encoding (interior: child-pair index,
+//                           leaf: flag|count|first slot);
 //                           sibling pairs share a 64-B line; all meshes concatenated, `first` rebased to global
 //                           node / triangle-slot indices
 //   tri_verts  float4[3*T]  per REORDERED primitive slot (BVH leaf order): v0,v1,v2; v0.w = global triangle id,
@@ -31,6 +33,7 @@
 // leaf with more prims (identical centroids, bvhtrimesh.h:235-238): 0xF0000000 | node index (node is re-fetched).
 #define AGPT_ENC_LEAF 0x80000000u
 #define AGPT_ENC_BIGLEAF 0xF0000000u
+#define AGPT_NODE_BIGLEAF 0x80000000u  // flag in a node record's count word: leaf too big for the inline encoding
 
 struct DevPrim {
     int32_t type;

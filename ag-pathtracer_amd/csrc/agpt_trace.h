@@ -137,10 +137,9 @@ __device__ __forceinline__ bool sphere_test(const DevPrim& P, const TraceRay& r,
     return sphere_test_c(V3(P.cx, P.cy, P.cz), P.r2, r, rayt, root_out);
 }
 
-__device__ __forceinline__ uint32_t encode_child(uint32_t node_index, uint32_t first, uint32_t count) {
-    if (count == 0) return first;                                  // interior: child-pair index
-    if (count <= 7 && first < 0x10000000u) return AGPT_ENC_LEAF | ((count - 1) << 28) | first;
-    return AGPT_ENC_BIGLEAF | node_index;
+// traversal encoding of a child from its node record's last two words (precomputed on the host, agpt_scene.h)
+__device__ __forceinline__ uint32_t encode_child(uint32_t node_index, uint32_t z, uint32_t w) {
+    return (w & AGPT_NODE_BIGLEAF) ? (AGPT_ENC_BIGLEAF | node_index) : z;
 }
 
 struct TraceCounters {
@@ -256,7 +255,7 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
                     const float4* np = sc.nodes + 2 * (size_t)(cur & 0x0FFFFFFFu);
                     float4 n1 = np[1];
                     first = __float_as_uint(n1.z);
-                    count = __float_as_uint(n1.w);
+                    count = __float_as_uint(n1.w) & ~AGPT_NODE_BIGLEAF;
                 } else {
                     first = cur & 0x0FFFFFFFu;
                     count = ((cur >> 28) & 7u) + 1u;
