@@ -28,7 +28,8 @@ EXPORTS = [
     "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_create_backdrop",
     "agpt_intersect_batch", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
-    "agpt_kat_bsdf_sample", "agpt_kat_rng",
+    "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
+    "agpt_obj_free", "agpt_obj_last_error",
 ]
 
 
@@ -114,6 +115,13 @@ def lib():
     L.agpt_kat_bsdf_eval.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
     L.agpt_kat_bsdf_sample.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp, fp, ip]
     L.agpt_kat_rng.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, fp, C.POINTER(C.c_uint32)]
+    L.agpt_obj_load.argtypes = [C.c_char_p, fp, C.c_int, C.POINTER(vp)]
+    L.agpt_obj_parse.argtypes = [C.c_char_p, C.c_size_t, fp, C.c_int, C.POINTER(vp)]
+    L.agpt_obj_counts.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+    L.agpt_obj_get.argtypes = [vp, fp, fp, fp, ip]
+    L.agpt_obj_free.argtypes = [vp]
+    L.agpt_obj_free.restype = None
+    L.agpt_obj_last_error.restype = C.c_char_p
     _LIB = L
     return L
 
@@ -164,6 +172,36 @@ def bvh_build(verts, indices, max_prims_in_node=1):
                                 order.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(total), C.byref(depth)),
            "agpt_bvh_build")
     return nodes[:total.value + 1].copy(), order, depth.value
+
+
+def load_obj(path=None, text=None, transform=None, ignore_normals=False):
+    """TriangleMesh::LoadObj (trianglemesh.cpp:157-230): returns (verts[n,3], normals[m,3] or None, uvs[k,2] or None,
+    indices[3*tris,3]) ready for Scene.add_mesh.  `transform` is a row-major 4x4 (mat4)."""
+    L = lib()
+    h = C.c_void_p()
+    tp = None
+    if transform is not None:
+        t = np.ascontiguousarray(transform, np.float32).reshape(16)
+        tp = t.ctypes.data_as(C.POINTER(C.c_float))
+    if text is not None:
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        rc = L.agpt_obj_parse(data, len(data), tp, int(bool(ignore_normals)), C.byref(h))
+    else:
+        rc = L.agpt_obj_load(os.fsencode(path), tp, int(bool(ignore_normals)), C.byref(h))
+    if rc < 0:
+        raise AgptError("load_obj failed (%d): %s" % (rc, L.agpt_obj_last_error().decode()))
+    try:
+        nv, nn, nt, ni = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.agpt_obj_counts(h, C.byref(nv), C.byref(nn), C.byref(nt), C.byref(ni))
+        v = np.zeros((nv.value, 3), np.float32)
+        n = np.zeros((nn.value, 3), np.float32)
+        t = np.zeros((nt.value, 2), np.float32)
+        ix = np.zeros((ni.value, 3), np.int32)
+        fp = C.POINTER(C.c_float)
+        L.agpt_obj_get(h, v.ctypes.data_as(fp), n.ctypes.data_as(fp), t.ctypes.data_as(fp), ix.ctypes.data_as(C.POINTER(C.c_int32)))
+    finally:
+        L.agpt_obj_free(h)
+    return v, (n if nn.value else None), (t if nt.value else None), ix
 
 
 class Context:

@@ -16,6 +16,7 @@
 #ifndef AGPT_H
 #define AGPT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -144,6 +145,19 @@ int agpt_bvh_build(const float* vertices, int n_vertices, const int32_t* indices
  * capacities: vertices/normals 3*2*(steps+5) floats, texcoords 2*2*(steps+5), indices 3*6*(steps+4) ints */
 int agpt_create_backdrop(const float origin[3], const float size[3], float radius, int steps, float* vertices,
                          float* normals, float* texcoords, int32_t* indices, int* n_vertices, int* n_indices);
+
+/* TriangleMesh::LoadObj (trianglemesh.cpp:157-230): OBJ text -> the four arrays agpt_scene_add_mesh takes.  Host-only.
+ * transform16 = row-major mat4 (template/precomp.h:845-1030) applied to points (TransformPoint) and, as inverse
+ * transpose, to normals; NULL = identity.  Polygons are triangulated like the tinyobjloader 2.0.0 the reference vendors.
+ * Errors (unreadable file, malformed / zero face index, face referencing a missing normal or texcoord) return
+ * AGPT_ERR_INVALID with agpt_obj_last_error() -- the reference calls exit(1) / reads out of bounds instead. */
+typedef struct agpt_obj_mesh agpt_obj_mesh;
+int agpt_obj_load(const char* path, const float* transform16, int ignore_normals, agpt_obj_mesh** out);
+int agpt_obj_parse(const char* text, size_t length, const float* transform16, int ignore_normals, agpt_obj_mesh** out);
+int agpt_obj_counts(const agpt_obj_mesh*, int* n_vertices, int* n_normals, int* n_texcoords, int* n_indices);
+int agpt_obj_get(const agpt_obj_mesh*, float* vertices, float* normals, float* texcoords, int32_t* indices);
+void agpt_obj_free(agpt_obj_mesh*);
+const char* agpt_obj_last_error(void);
 
 /* ---- hot path -------------------------------------------------------------------------------------- */
 /* Scene::Intersect (any_hit=0, scene.h:5-13) / Scene::IntersectP (any_hit=1, scene.h:15-19) for n rays.

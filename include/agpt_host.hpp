@@ -9,6 +9,7 @@
 //   DisneyMaterial::Make(color, rough, metallic)  material.h:60     agpt::DisneyMaterial::Make(scene, ...)
 //   MirrorMaterial::Make(r)                        material.h:83     agpt::MirrorMaterial::Make(scene, r)
 //   TriangleMesh::CreateBackdrop(...)              trianglemesh.cpp:232   agpt::TriangleMesh::CreateBackdrop(...)
+//   TriangleMesh::LoadObj(file, mat, transform)    trianglemesh.cpp:157   agpt::TriangleMesh::LoadObj(file, transform16)
 //   make_shared<BVHTriMesh>(mesh, mat, 1)          bvhtrimesh.h:154  scene.primitives_push_back(mesh, mat, 1)
 //   make_shared<Sphere>(c, r, mat)                 intersectable.h:161    scene.primitives_push_back(Sphere{c, r}, mat)
 //   scene->addAreaLight(sphere, L)                 scene.h:21        scene.addAreaLight(Sphere{c, r}, L)
@@ -63,6 +64,24 @@ private:
 struct TriangleMesh {
     std::vector<float> vertices, normals, texcoords;
     std::vector<int32_t> indices;
+
+    // TriangleMesh::LoadObj(inputfile, mat, transform, ignore_normals) (trianglemesh.cpp:157-230); transform16 is a
+    // row-major mat4 or nullptr for identity.  Throws agpt::Error where the reference calls exit(1).
+    static TriangleMesh LoadObj(const std::string& inputfile, const float* transform16 = nullptr, bool ignore_normals = false) {
+        agpt_obj_mesh* h = nullptr;
+        if (agpt_obj_load(inputfile.c_str(), transform16, ignore_normals ? 1 : 0, &h) < 0)
+            throw std::runtime_error(std::string("agpt_obj_load: ") + agpt_obj_last_error());
+        TriangleMesh m;
+        int nv = 0, nn = 0, nt = 0, ni = 0;
+        agpt_obj_counts(h, &nv, &nn, &nt, &ni);
+        m.vertices.resize(3 * (size_t)nv);
+        m.normals.resize(3 * (size_t)nn);
+        m.texcoords.resize(2 * (size_t)nt);
+        m.indices.resize(3 * (size_t)ni);
+        agpt_obj_get(h, m.vertices.data(), m.normals.data(), m.texcoords.data(), m.indices.data());
+        agpt_obj_free(h);
+        return m;
+    }
 
     static TriangleMesh CreateBackdrop(float3 origin, float3 size, float radius, int steps) {
         TriangleMesh m;
