@@ -24,7 +24,8 @@ NODE_DTYPE = np.dtype([("bmin", np.float32, 3), ("bmax", np.float32, 3), ("first
 EXPORTS = [
     "agpt_last_error", "agpt_version", "agpt_init", "agpt_set_stream", "agpt_destroy", "agpt_scene_create",
     "agpt_scene_destroy", "agpt_scene_add_material", "agpt_scene_add_mesh", "agpt_scene_add_sphere",
-    "agpt_scene_add_area_light", "agpt_scene_add_uniform_infinite_light", "agpt_scene_set_camera",
+    "agpt_scene_add_area_light", "agpt_scene_add_uniform_infinite_light", "agpt_scene_add_infinite_area_light",
+    "agpt_scene_set_camera",
     "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_create_backdrop",
     "agpt_intersect_batch", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
@@ -97,6 +98,7 @@ def lib():
     L.agpt_scene_add_sphere.argtypes = [vp, fp, C.c_float, C.c_int]
     L.agpt_scene_add_area_light.argtypes = [vp, fp, C.c_float, fp]
     L.agpt_scene_add_uniform_infinite_light.argtypes = [vp, fp]
+    L.agpt_scene_add_infinite_area_light.argtypes = [vp, fp, C.c_int, C.c_int]
     L.agpt_scene_set_camera.argtypes = [vp, C.POINTER(CameraDesc)]
     L.agpt_scene_commit.argtypes = [vp]
     L.agpt_mesh_num_nodes.argtypes = [vp, C.c_int]
@@ -309,6 +311,14 @@ class Scene:
         _, pl = _f(L)
         self.n_lights += 1
         return _check(self.L.agpt_scene_add_uniform_infinite_light(self.h, pl), "agpt_scene_add_uniform_infinite_light")
+
+    def add_infinite_area_light(self, rgb):
+        """InfiniteAreaLight from an in-memory HDR image rgb[H, W, 3] (lights.cpp:31-48)."""
+        img = np.ascontiguousarray(rgb, np.float32)
+        self.n_lights += 1
+        return _check(self.L.agpt_scene_add_infinite_area_light(self.h, img.ctypes.data_as(C.POINTER(C.c_float)),
+                                                                img.shape[1], img.shape[0]),
+                      "agpt_scene_add_infinite_area_light")
 
     def set_camera(self, lookfrom, lookat, vup, aspect_ratio, vfov=45.0, aperture=0.0):
         d = CameraDesc()

@@ -83,6 +83,7 @@ struct agpt_scene {
     std::vector<agpt::HostSphere> spheres;
     std::vector<agpt::HostPrim> prims;
     std::vector<agpt::HostLight> lights;
+    std::vector<agpt::HostEnv> envs;
     std::vector<DevMaterial> materials;
     DevCamera cam{};
     bool has_camera = false;
@@ -92,6 +93,9 @@ struct agpt_scene {
     DevBuf<DevPrim> d_prims;
     DevBuf<DevMaterial> d_materials;
     DevBuf<DevLight> d_lights;
+    DevBuf<DevEnv> d_envs;
+    std::vector<DevBuf<float4>> d_env_pixels;
+    std::vector<DevBuf<float>> d_env_func, d_env_cdf;
     DevScene dev{};
 };
 
@@ -217,6 +221,10 @@ void agpt_scene_destroy(agpt_scene* s) {
     s->d_prims.release();
     s->d_materials.release();
     s->d_lights.release();
+    s->d_envs.release();
+    for (auto& b : s->d_env_pixels) b.release();
+    for (auto& b : s->d_env_func) b.release();
+    for (auto& b : s->d_env_cdf) b.release();
     delete s;
 }
 
@@ -311,6 +319,20 @@ int agpt_scene_add_uniform_infinite_light(agpt_scene* s, const float L[3]) {
     return (int)s->lights.size() - 1;
 }
 
+int agpt_scene_add_infinite_area_light(agpt_scene* s, const float* rgb, int width, int height) {
+    if (!s || !rgb || width <= 0 || height <= 0 || (long long)width * height > (1ll << 28))
+        return fail(AGPT_ERR_INVALID, "agpt_scene_add_infinite_area_light: bad argument");
+    s->envs.push_back(agpt::make_env(rgb, width, height));
+    agpt::HostLight l;
+    l.type = AGPT_LIGHT_INFINITE_AREA;
+    l.shape = -1;
+    l.L = V3s(0.f);
+    l.env = (int)s->envs.size() - 1;
+    s->lights.push_back(l);
+    s->committed = false;
+    return (int)s->lights.size() - 1;
+}
+
 int agpt_scene_set_camera(agpt_scene* s, const agpt_camera_desc* d) {
     if (!s || !d) return fail(AGPT_ERR_INVALID, "agpt_scene_set_camera: NULL argument");
     s->cam = agpt::make_camera(*d);
@@ -336,7 +358,8 @@ int agpt_scene_commit(agpt_scene* s) {
         lights[i].L[0] = s->lights[i].L.x;
         lights[i].L[1] = s->lights[i].L.y;
         lights[i].L[2] = s->lights[i].L.z;
-        if (lights[i].type == AGPT_LIGHT_UNIFORM_INFINITE) n_inf++;
+        lights[i].env = s->lights[i].env;
+        if (lights[i].type != AGPT_LIGHT_AREA) n_inf++;
     }
     hipStream_t st = s->ctx->stream;
     int rc;
@@ -346,7 +369,26 @@ int agpt_scene_commit(agpt_scene* s) {
     if ((rc = upload(s->d_prims, flat.prims, st))) return rc;
     if ((rc = upload(s->d_materials, s->materials, st))) return rc;
     if ((rc = upload(s->d_lights, lights, st))) return rc;
+    std::vector<DevEnv> envs(s->envs.size());
+    s->d_env_pixels.resize(envs.size());
+    s->d_env_func.resize(envs.size());
+    s->d_env_cdf.resize(envs.size());
+    for (size_t i = 0; i < envs.size(); i++) {
+        const agpt::HostEnv& he = s->envs[i];
+        if ((rc = upload(s->d_env_pixels[i], he.pixels, st))) return rc;
+        if ((rc = upload(s->d_env_func[i], he.func, st))) return rc;
+        if ((rc = upload(s->d_env_cdf[i], he.cdf, st))) return rc;
+        envs[i].pixels = s->d_env_pixels[i].p;
+        envs[i].func = s->d_env_func[i].p;
+        envs[i].cdf = s->d_env_cdf[i].p;
+        envs[i].width = he.width;
+        envs[i].height = he.height;
+        envs[i].n = he.width * he.height;
+        envs[i].funcInt = he.funcInt;
+    }
+    if ((rc = upload(s->d_envs, envs, st))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
+    s->dev.envs = s->d_envs.p;
     s->dev.nodes = s->d_nodes.p;
     s->dev.tri_verts = s->d_tri_verts.p;
     s->dev.tri_shade = s->d_tri_shade.p;

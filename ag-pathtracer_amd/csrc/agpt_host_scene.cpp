@@ -255,6 +255,34 @@ DevCamera make_camera(const agpt_camera_desc& d) {
     return c;
 }
 
+HostEnv make_env(const float* rgb, int width, int height) {
+    HostEnv e;
+    e.width = width;
+    e.height = height;
+    const int n = width * height;
+    e.pixels.resize(n);
+    e.func.resize(n);
+    for (int idx = 0; idx < n; idx++) {
+        float4 p;
+        p.x = rgb[3 * idx]; p.y = rgb[3 * idx + 1]; p.z = rgb[3 * idx + 2]; p.w = 0.f;
+        e.pixels[idx] = p;
+        const int y = idx / width;
+        const float th = (y + .5f) * AGPT_PI / height;
+        const float max_component = smaxf(p.x, smaxf(p.y, p.z));
+        e.func[idx] = max_component * sinf(th);
+    }
+    e.cdf.resize((size_t)n + 1);
+    e.cdf[0] = 0;
+    for (int i = 1; i < n + 1; i++) e.cdf[i] = e.cdf[i - 1] + e.func[i - 1] / n;
+    e.funcInt = e.cdf[n];
+    if (e.funcInt == 0) {
+        for (int i = 1; i < n + 1; i++) e.cdf[i] = float(i) / float(n);
+    } else {
+        for (int i = 1; i < n + 1; i++) e.cdf[i] /= e.funcInt;
+    }
+    return e;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 static inline float4 F4(float x, float y, float z, float w) {
     float4 r;

@@ -41,7 +41,17 @@ struct HostLight {
     int type;
     int shape;
     v3 L;
+    int env = -1;
 };
+
+// InfiniteAreaLight ctor data (lights.cpp:31-48) + Distribution1D ctor (sampling.h:21-33)
+struct HostEnv {
+    int width = 0, height = 0;
+    std::vector<float4> pixels;
+    std::vector<float> func, cdf;
+    float funcInt = 0;
+};
+HostEnv make_env(const float* rgb, int width, int height);
 
 // BVHTriMesh ctor: Primitive list + BuildRecursive + FlattenBVHTree (bvhtrimesh.h:154-178,213-330)
 void build_bvh(HostMesh& mesh, int max_prims_in_node);

@@ -528,8 +528,8 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                 int hp = (hid & AGPT_HIT_SPHERE) ? (int)(hid & 0x7FFFFFFFu)
                                                  : (int)__float_as_uint(sc.tri_shade[4 * (size_t)hid + 3].w);
                 add = sc.prims[hp].arealight == (int)light;
-            } else {  // :86-87 light.Le(ray): non-zero only for the infinite light
-                add = sc.lights[light].type == AGPT_LIGHT_UNIFORM_INFINITE;
+            } else {  // :86-87 light.Le(ray): non-zero only for an IsInfinite() light
+                add = sc.lights[light].type != AGPT_LIGHT_AREA;
             }
             if (add) {
                 float4 c = pb.c2[pid];
@@ -562,8 +562,12 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                 v3 Le = al >= 0 ? mat_v3(sc.lights[al].L) : V3s(0.f);
                 L = L + beta * Le;
             } else {
-                for (int li = 0; li < sc.n_lights; li++)
-                    if (sc.lights[li].type == AGPT_LIGHT_UNIFORM_INFINITE) L = L + beta * mat_v3(sc.lights[li].L);
+                for (int li = 0; li < sc.n_lights; li++) {
+                    if (sc.lights[li].type == AGPT_LIGHT_UNIFORM_INFINITE)
+                        L = L + beta * mat_v3(sc.lights[li].L);
+                    else if (sc.lights[li].type == AGPT_LIGHT_INFINITE_AREA)
+                        L = L + beta * env_Le(&sc.envs[sc.lights[li].env], D);
+                }
             }
         }
         if (!found || (int)bounces >= rc.max_depth) {  // :150
@@ -609,6 +613,15 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                     visD = normalize(wi);
                     visT = AGPT_FLT_MAX;
                     Li = mat_v3(light.L);
+                } else if (light.type == AGPT_LIGHT_INFINITE_AREA) {  // lights.cpp:50-90: 1 extra draw, offset along n
+                    const DevEnv& env = sc.envs[light.env];
+                    Li = V3s(0.f);
+                    if (env_sample_li(&env, rng_float(rng), &wi, &lightPdf)) {
+                        visO = s.p + AGPT_EPSILON * s.n;
+                        visD = normalize(wi);
+                        visT = AGPT_FLT_MAX;
+                        Li = env_Le(&env, visD);
+                    }
                 } else {  // AreaLight::Sample_Li lights.cpp:115-126
                     v3 pS;
                     sphere_sample_ref(sc.prims[light.shape], s.p, uL0, uL1, &pS, &lightPdf);
@@ -669,25 +682,29 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                         float lp;
                         if (light.type == AGPT_LIGHT_UNIFORM_INFINITE)
                             lp = dot(s.n, wi) > 0 ? AGPT_INV2PI : 0.f;  // lights.cpp:26-28 (geometric n)
+                        else if (light.type == AGPT_LIGHT_INFINITE_AREA)
+                            lp = env_pdf_li(&sc.envs[light.env], wi);
                         else
                             lp = sphere_pdf(sc.prims[light.shape], s.p);
                         if (lp != 0) {
                             float weight = power_heuristic(1, pdf, 1, lp);
-                            v3 Li2 = mat_v3(light.L);  // Le(-wi) of the light's shape, or light.Le(ray) on a miss
-                            if (!isblack(Li2)) {
-                                v3 c2 = f * Li2 * weight / pdf;
-                                v3 mO = s.p + AGPT_EPSILON * wi;
-                                v3 mD = normalize(wi);
-                                float4 c4, mo4, md4;
-                                c4.x = c2.x; c4.y = c2.y; c4.z = c2.z; c4.w = 0.f;
-                                mo4.x = mO.x; mo4.y = mO.y; mo4.z = mO.z; mo4.w = AGPT_FLT_MAX;
-                                md4.x = mD.x; md4.y = mD.y; md4.z = mD.z; md4.w = 0.f;
-                                pb.c2[pid] = c4;
-                                pb.mis_o[pid] = mo4;
-                                pb.mis_d[pid] = md4;
-                                flags |= PF_PEND_C2;
-                                bits |= SB_MIS;
-                            }
+                            // Le(-wi) of the light's shape, or light.Le(ray) on a miss (ray.D = normalize(wi))
+                            v3 Li2 = light.type == AGPT_LIGHT_INFINITE_AREA ? env_Le(&sc.envs[light.env], normalize(wi))
+                                                                            : mat_v3(light.L);
+                            // the reference traces this ray before it looks at Li (integrator.h:77-88); a black Li only
+                            // means nothing is added afterwards
+                            v3 c2 = isblack(Li2) ? V3s(0.f) : f * Li2 * weight / pdf;
+                            v3 mO = s.p + AGPT_EPSILON * wi;
+                            v3 mD = normalize(wi);
+                            float4 c4, mo4, md4;
+                            c4.x = c2.x; c4.y = c2.y; c4.z = c2.z; c4.w = 0.f;
+                            mo4.x = mO.x; mo4.y = mO.y; mo4.z = mO.z; mo4.w = AGPT_FLT_MAX;
+                            md4.x = mD.x; md4.y = mD.y; md4.z = mD.z; md4.w = 0.f;
+                            pb.c2[pid] = c4;
+                            pb.mis_o[pid] = mo4;
+                            pb.mis_d[pid] = md4;
+                            flags |= PF_PEND_C2;
+                            bits |= SB_MIS;
                         }
                     }
                 } else if (isblack(f) || pdf == 0) {

@@ -117,6 +117,7 @@ AGPT_HD float cr_cosf(float x) {
     return c;
 }
 AGPT_HD float cr_acosf(float x) { return (float)acos((double)x); }
+AGPT_HD float cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
 
 // template/common.h:145-151
 AGPT_HD void coordinate_system(v3 v1, v3* v2, v3* v3o) {

@@ -22,6 +22,7 @@
 #define AGPT_PRIM_SPHERE 1
 #define AGPT_LIGHT_AREA 0
 #define AGPT_LIGHT_UNIFORM_INFINITE 1
+#define AGPT_LIGHT_INFINITE_AREA 2
 
 #define AGPT_HIT_MISS 0xFFFFFFFFu
 #define AGPT_HIT_SPHERE 0x80000000u
@@ -66,6 +67,16 @@ struct DevLight {
     int32_t type;
     int32_t shape;  // primitive index of the emitting sphere
     float L[3];
+    int32_t env;    // AGPT_LIGHT_INFINITE_AREA: index into DevScene::envs
+};
+
+// InfiniteAreaLight's HDRTexture + Distribution1D (lights.cpp:31-48, texture.h:41-84, sampling.h:19-69) in HBM
+struct DevEnv {
+    const float4* pixels;  // [height*width] rgb
+    const float* func;     // [n] max(rgb) * sin(theta_row)
+    const float* cdf;      // [n+1]
+    int32_t width, height, n;
+    float funcInt;
 };
 
 struct DevCamera {
@@ -80,6 +91,7 @@ struct DevScene {
     const DevPrim* prims;
     const DevMaterial* materials;
     const DevLight* lights;
+    const DevEnv* envs;
     int32_t n_prims, n_lights, n_materials;
     int32_t n_infinite;        // number of IsInfinite() lights
     int32_t n_meshes;          // non-empty mesh primitives

@@ -472,6 +472,84 @@ __device__ __forceinline__ float sphere_pdf(const DevPrim& P, v3 refp) {
     float cosThetaMax = sqrtf(smaxf(0.f, 1 - sinThetaMax2));
     return 1 / (2 * AGPT_PI * (1 - cosThetaMax));
 }
+// ---- InfiniteAreaLight (lights.cpp:50-112, #define ILS) ------------------------------------------------------
+__device__ __forceinline__ int env_mod(int a, int b) {  // HDRTexture::Mod texture.h:76-79
+    int result = a - (a / b) * b;
+    return (result < 0) ? result + b : result;
+}
+__device__ __forceinline__ v3 env_value(const DevEnv& e, float u, float v) {  // HDRTexture::value texture.h:59-67
+    int si = (int)floorf(u * e.width - .5f);
+    int ti = (int)floorf(v * e.height - .5f);
+    float4 p = e.pixels[env_mod(ti, e.height) * e.width + env_mod(si, e.width)];
+    return V3(p.x, p.y, p.z);
+}
+__device__ __forceinline__ float spherical_theta(v3 v) { return cr_acosf(tclampf(v.z, -1.f, 1.f)); }  // common.h:158-160
+__device__ __forceinline__ float spherical_phi(v3 v) {                                                // common.h:162-165
+    float p = cr_atan2f(v.y, v.x);
+    return (p < 0) ? (p + AGPT_TWOPI) : p;
+}
+__device__ __noinline__ v3 env_Le(const DevEnv* e, v3 D) {  // InfiniteAreaLight::Le lights.cpp:108-112
+    v3 w = normalize(D);
+    w = V3(w.x, w.z, w.y);
+    return env_value(*e, spherical_phi(w) * AGPT_INV2PI, spherical_theta(w) * AGPT_INVPI);
+}
+// Distribution1D::SampleContinuous (sampling.h:37-52) with FindInterval (:4-17)
+__device__ __forceinline__ float env_sample_continuous(const DevEnv& e, float u, float* pdf) {
+    int size = e.n + 1;
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (e.cdf[middle] <= u) {
+            first = middle + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    int offset = first - 1;
+    if (size - 2 < offset) offset = size - 2;
+    if (offset < 0) offset = 0;
+    float c0 = e.cdf[offset], c1 = e.cdf[offset + 1];
+    float du = u - c0;
+    if ((c1 - c0) > 0) du /= c1 - c0;
+    *pdf = (e.funcInt > 0) ? e.func[offset] / e.funcInt : 0;
+    return (offset + du) / e.n;
+}
+// InfiniteAreaLight::Sample_Li lights.cpp:50-90: wi and pdf for one uniform draw u; returns false when mapPdf == 0
+__device__ __noinline__ bool env_sample_li(const DevEnv* ep, float u, v3* wi, float* pdf) {
+    const DevEnv& e = *ep;
+    float mapPdf;
+    float sample = env_sample_continuous(e, u, &mapPdf);
+    if (mapPdf == 0) return false;
+    int idx = (int)(sample * e.n);
+    float uvx = ((idx % e.width) + .5f) / e.width;
+    float uvy = ((idx / e.width) + .5f) / e.height;
+    float theta = uvy * AGPT_PI, phi = uvx * AGPT_TWOPI;
+    float sinTheta, cosTheta, sinPhi, cosPhi;
+    cr_sincosf(theta, &sinTheta, &cosTheta);
+    cr_sincosf(phi, &sinPhi, &cosPhi);
+    *wi = V3(sinTheta * cosPhi, cosTheta, sinTheta * sinPhi);
+    *pdf = mapPdf / (2 * AGPT_PI * AGPT_PI * sinTheta);
+    if (sinTheta == 0) *pdf = 0;
+    return true;
+}
+// InfiniteAreaLight::Pdf_Li lights.cpp:92-106
+__device__ __noinline__ float env_pdf_li(const DevEnv* ep, v3 wi) {
+    const DevEnv& e = *ep;
+    v3 w = normalize(wi);
+    w = V3(w.x, w.z, w.y);
+    float theta = spherical_theta(w), phi = spherical_phi(w);
+    float sinTheta = cr_sinf(theta);
+    if (sinTheta == 0) return 0;
+    int x = (int)(phi * AGPT_INV2PI * e.width);
+    if (e.width - 1 < x) x = e.width - 1;
+    if (x < 0) x = 0;
+    int y = (int)(theta * AGPT_INVPI * e.height);
+    if (e.height - 1 < y) y = e.height - 1;
+    if (y < 0) y = 0;
+    float discrete = e.func[y * e.width + x] / (e.funcInt * e.n);
+    return e.n * discrete / (2 * AGPT_PI * AGPT_PI * sinTheta);
+}
+
 // integrator.h:33-36
 __device__ __forceinline__ float power_heuristic(int nf, float fPdf, int ng, float gPdf) {
     float f = nf * fPdf, g = ng * gPdf;

@@ -72,6 +72,11 @@ class SceneDesc:
         self.n_lights += 1
         return self.n_lights - 1
 
+    def add_infinite_area_light(self, rgb):
+        self.ops.append(("env_light", np.ascontiguousarray(rgb, F).copy()))
+        self.n_lights += 1
+        return self.n_lights - 1
+
     def set_camera(self, lookfrom, lookat, vup, aspect_ratio, vfov=45.0, aperture=0.0):
         self.camera = (np.asarray(lookfrom, F).copy(), np.asarray(lookat, F).copy(), np.asarray(vup, F).copy(),
                        F(aspect_ratio), float(vfov), float(aperture))
@@ -90,6 +95,8 @@ class SceneDesc:
                 target.add_area_light(op[1], op[2], op[3])
             elif k == "infinite_light":
                 target.add_uniform_infinite_light(op[1])
+            elif k == "env_light":
+                target.add_infinite_area_light(op[1])
         if self.camera is not None:
             target.set_camera(*self.camera)
         if hasattr(target, "commit"):
@@ -326,6 +333,40 @@ def scene_c3(scale=1.0, aspect=16.0 / 9.0, seed=0xA6A70003 & 0x7FFFFFFF, all_met
     d.add_area_light([7.0, 9.8, 0.8], 0.5, KEY_LIGHT * F(70))
     d.add_uniform_infinite_light([.4, .45, .5])
     d.set_camera([-13.2, 4.2, 5.4], [6.0, 4.0, -1.5], [0, 1, 0], aspect, 58.0, 0.0)
+    return d
+
+
+def synthetic_hdr(width=128, height=64, seed=0xA6A70009 & 0x7FFFFFFF):
+    """Stand-in for small_workshop_1k.hdr (myapp.cpp:113; no .hdr ships): a sky gradient with a warm sun patch, a few
+    window-like bright panels and mild noise, rgb[H, W, 3], values up to ~60."""
+    rng = np.random.RandomState(seed)
+    v = (np.arange(height) + 0.5) / height
+    u = (np.arange(width) + 0.5) / width
+    U, V = np.meshgrid(u, v)
+    sky = np.stack([0.35 + 0.3 * (1 - V), 0.45 + 0.35 * (1 - V), 0.6 + 0.4 * (1 - V)], -1)
+    ground = np.stack([0.25 * np.ones_like(V), 0.22 * np.ones_like(V), 0.18 * np.ones_like(V)], -1)
+    img = np.where((V < 0.55)[..., None], sky, ground)
+    sun = np.exp(-(((U - 0.3) * 2) ** 2 + (V - 0.22) ** 2) / 0.002)
+    img = img + sun[..., None] * np.array([60.0, 52.0, 40.0])
+    for (cu, cv) in ((0.62, 0.35), (0.78, 0.33), (0.9, 0.36)):
+        panel = ((np.abs(U - cu) < 0.03) & (np.abs(V - cv) < 0.06)).astype(np.float64)
+        img = img + panel[..., None] * np.array([6.0, 6.5, 7.5])
+    img = img * (1.0 + 0.05 * rng.standard_normal(img.shape))
+    return np.maximum(img, 0.0).astype(F)
+
+
+def scene_simple_test(hdr=None, backdrop=None, aperture=0.1):
+    """The reference's default scene, SimpleTestScene (myapp.cpp:55-114): backdrop + gold sphere lit ONLY by the HDR
+    environment light, thin-lens camera (aperture .1)."""
+    from .binding import create_backdrop
+    d = SceneDesc("SimpleTestScene")
+    floor = d.add_material(MAT_DISNEY, hex2lin(0xcbceb1), 1.0, 0.0)
+    gold = d.add_material(MAT_DISNEY, [0.944, 0.776, 0.373], 0.5, 1.0)
+    v, n, t, idx = backdrop if backdrop is not None else create_backdrop([0, -1, 20], [40, 20, 40], 7.5, 32)
+    d.add_mesh(v, n, t, idx, floor, 1)
+    d.add_sphere([0, 0, 0], 1.0, gold)
+    d.add_infinite_area_light(synthetic_hdr() if hdr is None else hdr)
+    d.set_camera([-1.46, 1.16, -4.64], [0, 0, 0], [0, 1, 0], 1.0, 45.0, aperture)
     return d
 
 

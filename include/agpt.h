@@ -126,6 +126,10 @@ int agpt_scene_add_sphere(agpt_scene*, const float center[3], float radius, int 
 int agpt_scene_add_area_light(agpt_scene*, const float center[3], float radius, const float L[3]);
 /* scene->lights.push_back(make_shared<UniformInfiniteLight>(L)) (lights.h:37-51): returns light index */
 int agpt_scene_add_uniform_infinite_light(agpt_scene*, const float L[3]);
+/* scene->lights.push_back(make_shared<InfiniteAreaLight>(texmap)) (lights.cpp:31-112 with ILS): the HDR environment map is
+ * passed as width*height RGB floats (row-major, row 0 = top), i.e. what stbi_loadf returns in the reference (texture.h:43-53);
+ * builds the max(rgb)*sin(theta) Distribution1D (sampling.h:19-69) on the host.  returns light index */
+int agpt_scene_add_infinite_area_light(agpt_scene*, const float* rgb, int width, int height);
 /* scene->camera = desc; Camera(desc) (camera.h:29-56,77-90) */
 int agpt_scene_set_camera(agpt_scene*, const agpt_camera_desc*);
 /* flatten + upload to HBM; must be called after the last add_* and before render/intersect */

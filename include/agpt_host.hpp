@@ -14,6 +14,7 @@
 //   make_shared<Sphere>(c, r, mat)                 intersectable.h:161    scene.primitives_push_back(Sphere{c, r}, mat)
 //   scene->addAreaLight(sphere, L)                 scene.h:21        scene.addAreaLight(Sphere{c, r}, L)
 //   scene->lights.push_back(UniformInfiniteLight)  lights.h:37       scene.lights_push_back(UniformInfiniteLight{L})
+//   scene->lights.push_back(InfiniteAreaLight(hdr)) lights.h:53      scene.lights_push_back(InfiniteAreaLight{rgb, w, h})
 //   scene->camera = CameraDesc{...}                camera.h:17       scene.camera = ...; (applied at commit)
 //   Scene::Intersect / IntersectP                  scene.h:5-19      scene.Intersect(rays, n, hits) / IntersectP
 //   PathTracer(maxDepth).Li per pixel + Accumulator::AddSample       agpt::PathTracer(maxDepth).Render(scene, accum, spp)
@@ -106,6 +107,11 @@ struct Sphere {
 struct UniformInfiniteLight {
     float3 L;
 };
+// InfiniteAreaLight (lights.h:53-70): the HDR environment map as width*height RGB floats (what stbi_loadf returns)
+struct InfiniteAreaLight {
+    const float* rgb;
+    int width, height;
+};
 using CameraDesc = agpt_camera_desc;
 
 class Scene {
@@ -141,6 +147,9 @@ public:
     int lights_push_back(const UniformInfiniteLight& l) {
         const float c[3] = {l.L.x, l.L.y, l.L.z};
         return check(agpt_scene_add_uniform_infinite_light(h_, c), "agpt_scene_add_uniform_infinite_light");
+    }
+    int lights_push_back(const InfiniteAreaLight& l) {
+        return check(agpt_scene_add_infinite_area_light(h_, l.rgb, l.width, l.height), "agpt_scene_add_infinite_area_light");
     }
     // upload to HBM; call once after the scene is built (and again after changing `camera`)
     void commit() {

@@ -69,6 +69,8 @@ int oracle_add_sphere(oracle_scene*, const float center[3], float radius, int ma
 int oracle_add_area_light(oracle_scene*, const float center[3], float radius, const float L[3]);
 /* scene.lights.push_back(make_shared<UniformInfiniteLight>(L)) */
 int oracle_add_uniform_infinite_light(oracle_scene*, const float L[3]);
+/* scene.lights.push_back(make_shared<InfiniteAreaLight>(texmap)) with the HDR image given as W*H RGB floats */
+int oracle_add_infinite_area_light(oracle_scene*, const float* rgb, int width, int height);
 /* CameraDesc + Camera ctor (camera.h:17-56,77-90) */
 void oracle_set_camera(oracle_scene*, const float lookfrom[3], const float lookat[3], const float vup[3],
                        float aspect_ratio, float vfov, float aperture);

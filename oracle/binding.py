@@ -61,6 +61,7 @@ def lib():
     L.oracle_add_sphere.argtypes = [C.c_void_p, fp, C.c_float, C.c_int]
     L.oracle_add_area_light.argtypes = [C.c_void_p, fp, C.c_float, fp]
     L.oracle_add_uniform_infinite_light.argtypes = [C.c_void_p, fp]
+    L.oracle_add_infinite_area_light.argtypes = [C.c_void_p, fp, C.c_int, C.c_int]
     L.oracle_set_camera.argtypes = [C.c_void_p, fp, fp, fp, C.c_float, C.c_float, C.c_float]
     L.oracle_set_max_depth.argtypes = [C.c_void_p, C.c_int]
     L.oracle_mesh_num_nodes.argtypes = [C.c_void_p, C.c_int]
@@ -182,6 +183,11 @@ class OracleScene:
     def add_uniform_infinite_light(self, L):
         l, pl = _f(L)
         return self.L.oracle_add_uniform_infinite_light(self.h, pl)
+
+    def add_infinite_area_light(self, rgb):
+        img = np.ascontiguousarray(rgb, np.float32)
+        h, w = img.shape[0], img.shape[1]
+        return self.L.oracle_add_infinite_area_light(self.h, img.ctypes.data_as(C.POINTER(C.c_float)), w, h)
 
     def set_camera(self, lookfrom, lookat, vup, aspect_ratio, vfov=45.0, aperture=0.0):
         a, pa = _f(lookfrom)

@@ -70,6 +70,7 @@ void oracle_set_trig_mode(int mode) { g_trig_mode = mode; }
 static inline float o_sinf(float x) { return g_trig_mode ? (float)sin((double)x) : sinf(x); }
 static inline float o_cosf(float x) { return g_trig_mode ? (float)cos((double)x) : cosf(x); }
 static inline float o_acosf(float x) { return g_trig_mode ? (float)acos((double)x) : acosf(x); }
+static inline float o_atan2f(float y, float x) { return g_trig_mode ? (float)atan2((double)y, (double)x) : atan2f(y, x); }
 
 /* ------------------------------------------------------------------------------------------------
  * template/common.h samplers
@@ -277,11 +278,21 @@ typedef struct {
     int arealight; /* index into lights, -1 = none */
 } ScenePrim;
 
-enum { LIGHT_AREA = 0, LIGHT_UNIFORM_INFINITE = 1 };
+enum { LIGHT_AREA = 0, LIGHT_UNIFORM_INFINITE = 1, LIGHT_INFINITE_AREA = 2 };
+/* HDRTexture (texture.h:41-84) + Distribution1D (sampling.h:19-69) of an InfiniteAreaLight (lights.cpp:31-48) */
+typedef struct {
+    int width, height;
+    f3* pixels;
+    float* func; /* [n] */
+    float* cdf;  /* [n+1] */
+    float funcInt;
+    int n;
+} EnvMap;
 typedef struct {
     int type;
     int shape; /* scene primitive index (area lights) */
     f3 Lemit;
+    EnvMap* env; /* LIGHT_INFINITE_AREA */
 } Light;
 
 typedef struct {
@@ -311,6 +322,8 @@ void oracle_scene_free(oracle_scene* s) {
         free(m->vertices); free(m->normals); free(m->texcoords); free(m->indices);
         free(m->primitives); free(m->nodes);
     }
+    for (int i = 0; i < s->n_lights; i++)
+        if (s->lights[i].env) { free(s->lights[i].env->pixels); free(s->lights[i].env->func); free(s->lights[i].env->cdf); free(s->lights[i].env); }
     free(s->materials); free(s->meshes); free(s->spheres); free(s->prims); free(s->lights);
     free(s);
 }
@@ -562,13 +575,43 @@ int oracle_add_sphere(oracle_scene* s, const float center[3], float radius, int 
 int oracle_add_area_light(oracle_scene* s, const float center[3], float radius, const float L[3]) { /* scene.h:21-25 */
     int prim = oracle_add_sphere(s, center, radius, -1);
     Light* l = PUSH(s->lights, s->n_lights, Light);
-    l->type = LIGHT_AREA; l->shape = prim; l->Lemit = F3(L[0], L[1], L[2]);
+    l->type = LIGHT_AREA; l->shape = prim; l->Lemit = F3(L[0], L[1], L[2]); l->env = NULL;
     s->prims[prim].arealight = s->n_lights - 1;
     return prim;
 }
 int oracle_add_uniform_infinite_light(oracle_scene* s, const float L[3]) {
     Light* l = PUSH(s->lights, s->n_lights, Light);
-    l->type = LIGHT_UNIFORM_INFINITE; l->shape = -1; l->Lemit = F3(L[0], L[1], L[2]);
+    l->type = LIGHT_UNIFORM_INFINITE; l->shape = -1; l->Lemit = F3(L[0], L[1], L[2]); l->env = NULL;
+    return s->n_lights - 1;
+}
+
+/* InfiniteAreaLight ctor (lights.cpp:31-48, #define ILS on) from an in-memory RGB float image (the reference loads it
+ * with stbi_loadf; no .hdr asset ships) + Distribution1D ctor (sampling.h:21-33) */
+int oracle_add_infinite_area_light(oracle_scene* s, const float* rgb, int width, int height) {
+    EnvMap* e = (EnvMap*)calloc(1, sizeof(EnvMap));
+    e->width = width; e->height = height; e->n = width * height;
+    e->pixels = (f3*)malloc(sizeof(f3) * (size_t)e->n);
+    for (int i = 0; i < e->n; i++) e->pixels[i] = F3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    e->func = (float*)malloc(sizeof(float) * (size_t)e->n);
+    for (int idx = 0; idx < e->n; idx++) {
+        int y = idx / width;
+        float th = (y + .5f) * O_PI / height;
+        f3 value = e->pixels[idx];
+        float maxComponent = s_maxf(value.x, s_maxf(value.y, value.z));
+        e->func[idx] = maxComponent * sinf(th); /* host-side: libm in both trig modes */
+    }
+    int n = e->n;
+    e->cdf = (float*)malloc(sizeof(float) * ((size_t)n + 1));
+    e->cdf[0] = 0;
+    for (int i = 1; i < n + 1; i++) e->cdf[i] = e->cdf[i - 1] + e->func[i - 1] / n;
+    e->funcInt = e->cdf[n];
+    if (e->funcInt == 0) {
+        for (int i = 1; i < n + 1; i++) e->cdf[i] = (float)i / (float)n;
+    } else {
+        for (int i = 1; i < n + 1; i++) e->cdf[i] /= e->funcInt;
+    }
+    Light* l = PUSH(s->lights, s->n_lights, Light);
+    l->type = LIGHT_INFINITE_AREA; l->shape = -1; l->Lemit = F3s(0.f); l->env = e;
     return s->n_lights - 1;
 }
 
@@ -1269,8 +1312,73 @@ static f3 si_Le(const oracle_scene* s, const SurfaceInteraction* si) {
 /* ------------------------------------------------------------------------------------------------
  * Lights -- lights.cpp:10-28 (VisibilityTester, UniformInfiniteLight), :115-130 (AreaLight)
  * ---------------------------------------------------------------------------------------------- */
+/* texture.h:76-79,59-67 HDRTexture::value / Mod */
+static int env_mod(int a, int b) {
+    int result = a - (a / b) * b;
+    return (result < 0) ? result + b : result;
+}
+static f3 env_value(const EnvMap* e, float u, float v) {
+    int si = (int)floorf(u * e->width - .5f);
+    int ti = (int)floorf(v * e->height - .5f);
+    return e->pixels[env_mod(ti, e->height) * e->width + env_mod(si, e->width)];
+}
+/* common.h:158-165 */
+static float spherical_theta(f3 v) { return o_acosf(t_clampf(v.z, -1.f, 1.f)); }
+static float spherical_phi(f3 v) {
+    float p = o_atan2f(v.y, v.x);
+    return (p < 0) ? (p + O_TWOPI) : p;
+}
+/* InfiniteAreaLight::Le lights.cpp:108-112 */
+static f3 env_Le(const EnvMap* e, f3 D) {
+    f3 w = f3_normalize(D);
+    w = F3(w.x, w.z, w.y);
+    return env_value(e, spherical_phi(w) * O_INV2PI, spherical_theta(w) * O_INVPI);
+}
+/* sampling.h:4-17 FindInterval with pred(index) = cdf[index] <= u */
+static int env_find_interval(const EnvMap* e, float u) {
+    int size = e->n + 1;
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (e->cdf[middle] <= u) {
+            first = middle + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    int r = first - 1;
+    if (size - 2 < r) r = size - 2; /* clamp(int): max(a, min(f, b)) */
+    if (r < 0) r = 0;
+    return r;
+}
+/* Distribution1D::SampleContinuous sampling.h:37-52 */
+static float env_sample_continuous(const EnvMap* e, float u, float* pdf) {
+    int offset = env_find_interval(e, u);
+    float du = u - e->cdf[offset];
+    if ((e->cdf[offset + 1] - e->cdf[offset]) > 0) du /= e->cdf[offset + 1] - e->cdf[offset];
+    *pdf = (e->funcInt > 0) ? e->func[offset] / e->funcInt : 0;
+    return (offset + du) / e->n;
+}
+
 static f3 light_sample_li(const oracle_scene* s, const Light* l, const SurfaceInteraction* ref, f2 u, f3* wi,
                           float* pdf, Ray* vis, octx* c) {
+    if (l->type == LIGHT_INFINITE_AREA) { /* lights.cpp:50-90 (ILS): ignores u, 1 extra draw */
+        const EnvMap* e = l->env;
+        float mapPdf;
+        float sample = env_sample_continuous(e, rng_float(c), &mapPdf);
+        if (mapPdf == 0) return F3s(0.f);
+        int idx = (int)(sample * e->n);
+        float uvx = ((idx % e->width) + .5f) / e->width;
+        float uvy = ((idx / e->width) + .5f) / e->height;
+        float theta = uvy * O_PI, phi = uvx * O_TWOPI;
+        float cosTheta = o_cosf(theta), sinTheta = o_sinf(theta);
+        float sinPhi = o_sinf(phi), cosPhi = o_cosf(phi);
+        *wi = F3(sinTheta * cosPhi, cosTheta, sinTheta * sinPhi);
+        *pdf = mapPdf / (2 * O_PI * O_PI * sinTheta);
+        if (sinTheta == 0) *pdf = 0;
+        *vis = make_ray(f3_add(ref->p, f3_muls(ref->n, O_EPSILON)), *wi, FLT_MAX); /* quirk 4: offset along n */
+        return env_Le(e, vis->D);
+    }
     if (l->type == LIGHT_UNIFORM_INFINITE) {
         *wi = random_in_hemisphere(c, ref->shading.n); /* quirk 3: ignores u, 2 extra draws */
         *pdf = O_INV2PI;
@@ -1291,9 +1399,29 @@ static f3 light_sample_li(const oracle_scene* s, const Light* l, const SurfaceIn
 }
 static float light_pdf_li(const oracle_scene* s, const Light* l, const SurfaceInteraction* ref, f3 wi) {
     if (l->type == LIGHT_UNIFORM_INFINITE) return f3_dot(ref->n, wi) > 0 ? O_INV2PI : 0.f;
+    if (l->type == LIGHT_INFINITE_AREA) { /* lights.cpp:92-106 */
+        const EnvMap* e = l->env;
+        f3 w = f3_normalize(wi);
+        w = F3(w.x, w.z, w.y);
+        float theta = spherical_theta(w), phi = spherical_phi(w);
+        float sinTheta = o_sinf(theta);
+        if (sinTheta == 0) return 0;
+        int x = (int)(phi * O_INV2PI * e->width);
+        if (e->width - 1 < x) x = e->width - 1;
+        if (x < 0) x = 0;
+        int y = (int)(theta * O_INVPI * e->height);
+        if (e->height - 1 < y) y = e->height - 1;
+        if (y < 0) y = 0;
+        float discrete = e->func[y * e->width + x] / (e->funcInt * e->n); /* DiscretePDF sampling.h:63-65 */
+        return e->n * discrete / (2 * O_PI * O_PI * sinTheta);
+    }
     return sphere_pdf(&s->spheres[s->prims[l->shape].index], ref, wi);
 }
-static f3 light_Le(const Light* l) { return l->type == LIGHT_UNIFORM_INFINITE ? l->Lemit : F3s(0.f); }
+static f3 light_Le(const Light* l, f3 D) {
+    if (l->type == LIGHT_UNIFORM_INFINITE) return l->Lemit;
+    if (l->type == LIGHT_INFINITE_AREA) return env_Le(l->env, D);
+    return F3s(0.f);
+}
 
 /* ------------------------------------------------------------------------------------------------
  * integrator.h -- PowerHeuristic :33-36, EstimateDirect :38-93, UniformSampleOneLight :95-105,
@@ -1339,7 +1467,7 @@ static f3 EstimateDirect(const oracle_scene* s, const SurfaceInteraction* si, f2
             if (found) {
                 if (s->prims[lightIsect.shape].arealight == lightIdx) Li2 = si_Le(s, &lightIsect);
             } else
-                Li2 = light_Le(light);
+                Li2 = light_Le(light, ray.D);
             if (!f3_isblack(Li2)) Ld = f3_add(Ld, f3_divs(f3_muls(f3_mul(f, Li2), weight), scatteringPdf));
         }
     }
@@ -1372,7 +1500,7 @@ static f3 PathTracer_Li(const oracle_scene* s, const Ray* r, octx* c) {
                 L = f3_add(L, f3_mul(beta, si_Le(s, &isect)));
             } else {
                 for (int i = 0; i < s->n_lights; i++)
-                    if (s->lights[i].type == LIGHT_UNIFORM_INFINITE) L = f3_add(L, f3_mul(beta, light_Le(&s->lights[i])));
+                    if (s->lights[i].type != LIGHT_AREA) L = f3_add(L, f3_mul(beta, light_Le(&s->lights[i], ray.D)));
             }
         }
         if (!foundIntersection || bounces >= s->MaxDepth) break;
