@@ -4,7 +4,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <future>
+#include <thread>
 
 namespace agpt {
 
@@ -71,14 +74,14 @@ struct BuildPrim {
 constexpr int kBuckets = 12;
 
 struct Builder {
-    std::vector<BuildPrim> prims;
+    std::vector<BuildPrim>& prims;  // shared; every task works on its own [start, end) range
     std::vector<agpt_bvh_node>& nodes;
     int max_prims;
     int next_pair = 2;
     int total = 0;
     int max_depth = 0;
 
-    Builder(std::vector<agpt_bvh_node>& n, int mp) : nodes(n), max_prims(mp) {}
+    Builder(std::vector<agpt_bvh_node>& n, std::vector<BuildPrim>& p, int mp) : prims(p), nodes(n), max_prims(mp) {}
 
     static int bucket_of(const Box& cb, const BuildPrim& p, int axis) {
         int b = (int)(kBuckets * cb.offset(p.c[axis], axis));
@@ -95,61 +98,65 @@ struct Builder {
         max_depth = std::max(max_depth, depth);
     }
 
-    void build(int start, int end, int slot, int depth) {
-        total++;
-        Box bounds;
+    // the split decision of BuildRecursive (bvhtrimesh.h:217-305): returns the partition point, or -1 for a leaf;
+    // `bounds` receives the node's primitive bounds.  Reorders prims[start, end).
+    int choose_split(int start, int end, Box& bounds) {
+        bounds = Box();
         for (int i = start; i < end; i++) bounds.grow(prims[i].box);
         const int n = end - start;
-        if (n == 1) return leaf(slot, start, n, bounds, depth);
-
+        if (n == 1) return -1;
         Box cb;
         for (int i = start; i < end; i++) cb.grow(V3(prims[i].c[0], prims[i].c[1], prims[i].c[2]));
         const int axis = cb.longest_axis();
-        if (cb.lo[axis] == cb.hi[axis]) return leaf(slot, start, n, bounds, depth);
-
+        if (cb.lo[axis] == cb.hi[axis]) return -1;
         int mid = (start + end) / 2;
         if (n <= 2) {
             std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end,
                              [axis](const BuildPrim& a, const BuildPrim& b) { return a.c[axis] < b.c[axis]; });
-        } else {
-            int count[kBuckets] = {0};
-            Box bb[kBuckets];
-            for (int i = start; i < end; i++) {
-                int b = bucket_of(cb, prims[i], axis);
-                count[b]++;
-                bb[b].grow(prims[i].box);
-            }
-            float cost[kBuckets - 1];
-            for (int i = 0; i < kBuckets - 1; i++) {
-                Box b0, b1;
-                int c0 = 0, c1 = 0;
-                for (int j = 0; j <= i; j++) {
-                    b0.grow(bb[j]);
-                    c0 += count[j];
-                }
-                for (int j = i + 1; j < kBuckets; j++) {
-                    b1.grow(bb[j]);
-                    c1 += count[j];
-                }
-                cost[i] = 1 + (c0 * b0.area() + c1 * b1.area()) / bounds.area();
-            }
-            float min_cost = cost[0];
-            int split = 0;
-            for (int i = 1; i < kBuckets - 1; i++)
-                if (cost[i] < min_cost) {
-                    min_cost = cost[i];
-                    split = i;
-                }
-            const float leaf_cost = (float)n;
-            if (n > max_prims || min_cost < leaf_cost) {
-                BuildPrim* pmid = std::partition(&prims[start], &prims[end - 1] + 1, [&](const BuildPrim& p) {
-                    return bucket_of(cb, p, axis) <= split;
-                });
-                mid = (int)(pmid - &prims[0]);
-            } else {
-                return leaf(slot, start, n, bounds, depth);
-            }
+            return mid;
         }
+        int count[kBuckets] = {0};
+        Box bb[kBuckets];
+        for (int i = start; i < end; i++) {
+            int b = bucket_of(cb, prims[i], axis);
+            count[b]++;
+            bb[b].grow(prims[i].box);
+        }
+        float cost[kBuckets - 1];
+        for (int i = 0; i < kBuckets - 1; i++) {
+            Box b0, b1;
+            int c0 = 0, c1 = 0;
+            for (int j = 0; j <= i; j++) {
+                b0.grow(bb[j]);
+                c0 += count[j];
+            }
+            for (int j = i + 1; j < kBuckets; j++) {
+                b1.grow(bb[j]);
+                c1 += count[j];
+            }
+            cost[i] = 1 + (c0 * b0.area() + c1 * b1.area()) / bounds.area();
+        }
+        float min_cost = cost[0];
+        int split = 0;
+        for (int i = 1; i < kBuckets - 1; i++)
+            if (cost[i] < min_cost) {
+                min_cost = cost[i];
+                split = i;
+            }
+        const float leaf_cost = (float)n;
+        if (n > max_prims || min_cost < leaf_cost) {
+            BuildPrim* pmid = std::partition(&prims[start], &prims[end - 1] + 1,
+                                             [&](const BuildPrim& p) { return bucket_of(cb, p, axis) <= split; });
+            return (int)(pmid - &prims[0]);
+        }
+        return -1;
+    }
+
+    void build(int start, int end, int slot, int depth) {
+        total++;
+        Box bounds;
+        const int mid = choose_split(start, end, bounds);
+        if (mid < 0) return leaf(slot, start, end - start, bounds, depth);
         const int first = next_pair;
         next_pair += 2;
         build(start, mid, first, depth + 1);
@@ -164,25 +171,84 @@ struct Builder {
     }
 };
 
+// A subtree built on its own: `nodes` in the layout the sequential builder produces for a tree of its own (root at 0,
+// slot 1 unused, child pairs from 2).  Embedding it below a parent only rebases the interior `first` fields, because the
+// reference's flatten hands out pair slots in pre-order: parent pair, then every pair of the left subtree, then the right.
+struct SubTree {
+    std::vector<agpt_bvh_node> nodes;  // total + 1 entries
+    int total = 0;
+    int max_depth = 0;
+};
+
+SubTree build_subtree(std::vector<BuildPrim>& shared, int start, int end, int max_prims, int depth, int par_levels) {
+    SubTree out;
+    const int n = end - start;
+    if (par_levels <= 0 || n < (1 << 16)) {
+        // sequential: the Builder works on the shared primitive array in place (disjoint ranges per task)
+        out.nodes.assign((size_t)2 * n + 2, agpt_bvh_node{});
+        Builder b(out.nodes, shared, max_prims);
+        b.build(start, end, 0, depth);
+        out.total = b.total;
+        out.max_depth = b.max_depth;
+        out.nodes.resize((size_t)b.total + 1);
+        return out;
+    }
+    std::vector<agpt_bvh_node> scratch(2);
+    Builder top(scratch, shared, max_prims);
+    Box bounds;
+    const int mid = top.choose_split(start, end, bounds);
+    if (mid < 0) return build_subtree(shared, start, end, max_prims, depth, 0);
+    auto fut = std::async(std::launch::async, [&]() { return build_subtree(shared, start, mid, max_prims, depth + 1, par_levels - 1); });
+    SubTree R = build_subtree(shared, mid, end, max_prims, depth + 1, par_levels - 1);
+    SubTree L = fut.get();
+    out.total = 1 + L.total + R.total;
+    out.max_depth = std::max(L.max_depth, R.max_depth);
+    out.nodes.resize((size_t)out.total + 1);
+    // children at slots 2,3; left's pairs follow from 4, right's after them
+    const int baseL = 4, baseR = 4 + (L.total - 1);
+    auto embed = [&](const SubTree& T, int root_slot, int base) {
+        for (int i = 0; i <= T.total; i++) {
+            if (i == 1) continue;
+            agpt_bvh_node nd = T.nodes[i];
+            if (nd.count == 0) nd.first = base + (nd.first - 2);
+            out.nodes[i == 0 ? root_slot : base + (i - 2)] = nd;
+        }
+    };
+    embed(L, 2, baseL);
+    embed(R, 3, baseR);
+    agpt_bvh_node& nd = out.nodes[0];
+    for (int a = 0; a < 3; a++) {
+        nd.bmin[a] = tminf(out.nodes[2].bmin[a], out.nodes[3].bmin[a]);
+        nd.bmax[a] = tmaxf(out.nodes[2].bmax[a], out.nodes[3].bmax[a]);
+    }
+    nd.first = 2;
+    nd.count = 0;
+    return out;
+}
+
 }  // namespace
 
 void build_bvh(HostMesh& mesh, int max_prims_in_node) {
     const int n_tris = (int)mesh.indices.size() / 9;
-    mesh.nodes.assign((size_t)2 * n_tris + 2, agpt_bvh_node{});
-    Builder b(mesh.nodes, max_prims_in_node);
-    b.prims.resize(n_tris);
+    std::vector<BuildPrim> prims(n_tris);
     for (int t = 0; t < n_tris; t++) {
-        BuildPrim& p = b.prims[t];
+        BuildPrim& p = prims[t];
         p.index = 3 * t;
         for (int k = 0; k < 3; k++) p.box.grow(mesh.vertices[mesh.indices[9 * t + 3 * k]]);
         for (int a = 0; a < 3; a++) p.c[a] = (p.box.lo[a] + p.box.hi[a]) * 0.5f;
     }
-    b.build(0, n_tris, 0, 0);
-    mesh.total_nodes = b.total;
-    mesh.max_depth = b.max_depth;
-    mesh.nodes.resize((size_t)b.total + 1);
+    // the top levels of the recursion fan out over host threads (subtrees touch disjoint primitive ranges); the result
+    // is byte-identical to the sequential build
+    int par_levels = 0;
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (const char* e = std::getenv("AGPT_BVH_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+    while ((1u << par_levels) < hw && par_levels < 5) par_levels++;
+    SubTree tree = build_subtree(prims, 0, n_tris, max_prims_in_node, 0, par_levels);
+    mesh.nodes.swap(tree.nodes);
+    mesh.total_nodes = tree.total;
+    mesh.max_depth = tree.max_depth;
     mesh.prim_index.resize(n_tris);
-    for (int t = 0; t < n_tris; t++) mesh.prim_index[t] = b.prims[t].index;
+    for (int t = 0; t < n_tris; t++) mesh.prim_index[t] = prims[t].index;
 }
 
 // ------------------------------------------------------------------------------------------------------------
