@@ -24,7 +24,7 @@ NODE_DTYPE = np.dtype([("bmin", np.float32, 3), ("bmax", np.float32, 3), ("first
 EXPORTS = [
     "agpt_last_error", "agpt_version", "agpt_init", "agpt_set_stream", "agpt_destroy", "agpt_scene_create",
     "agpt_scene_destroy", "agpt_scene_add_material", "agpt_scene_add_mesh", "agpt_scene_add_sphere",
-    "agpt_scene_add_area_light", "agpt_scene_add_uniform_infinite_light", "agpt_scene_add_infinite_area_light",
+    "agpt_scene_add_plane", "agpt_scene_add_area_light", "agpt_scene_add_uniform_infinite_light", "agpt_scene_add_infinite_area_light",
     "agpt_scene_set_camera",
     "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_create_backdrop",
     "agpt_intersect_batch", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
@@ -96,6 +96,7 @@ def lib():
     L.agpt_scene_add_material.argtypes = [vp, C.c_int, fp, C.c_float, C.c_float]
     L.agpt_scene_add_mesh.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, C.c_int, ip, C.c_int, C.c_int, C.c_int]
     L.agpt_scene_add_sphere.argtypes = [vp, fp, C.c_float, C.c_int]
+    L.agpt_scene_add_plane.argtypes = [vp, fp, fp, C.c_int]
     L.agpt_scene_add_area_light.argtypes = [vp, fp, C.c_float, fp]
     L.agpt_scene_add_uniform_infinite_light.argtypes = [vp, fp]
     L.agpt_scene_add_infinite_area_light.argtypes = [vp, fp, C.c_int, C.c_int]
@@ -297,6 +298,12 @@ class Scene:
     def add_sphere(self, center, radius, material):
         _, p = _f(center)
         return _check(self.L.agpt_scene_add_sphere(self.h, p, float(radius), int(material)), "agpt_scene_add_sphere")
+
+    def add_plane(self, o, size, material):
+        """scene->primitives.push_back(make_shared<Plane>(o, size, material)) (intersectable.h:119-157)."""
+        _, po = _f(o)
+        _, ps = _f(size)
+        return _check(self.L.agpt_scene_add_plane(self.h, po, ps, int(material)), "agpt_scene_add_plane")
 
     def addAreaLight(self, center, radius, L):
         """Scene::addAreaLight(make_shared<Sphere>(center, radius, nullptr), L)."""

@@ -295,6 +295,24 @@ int agpt_scene_add_sphere(agpt_scene* s, const float center[3], float radius, in
     return (int)s->prims.size() - 1;
 }
 
+int agpt_scene_add_plane(agpt_scene* s, const float o[3], const float size[2], int material) {
+    if (!s || !o || !size) return fail(AGPT_ERR_INVALID, "agpt_scene_add_plane: NULL argument");
+    if (material < -1 || material >= (int)s->materials.size()) return fail(AGPT_ERR_INVALID, "agpt_scene_add_plane: bad material id");
+    agpt::HostSphere sp;  // reused record: center = O, r = HalfSize.x, r2 = HalfSize.y
+    sp.center = V3(o[0], o[1], o[2]);
+    sp.r = size[0] / 2;
+    sp.r2 = size[1] / 2;
+    s->spheres.push_back(sp);
+    agpt::HostPrim p;
+    p.type = AGPT_PRIM_PLANE;
+    p.index = (int)s->spheres.size() - 1;
+    p.material = material;
+    p.arealight = -1;
+    s->prims.push_back(p);
+    s->committed = false;
+    return (int)s->prims.size() - 1;
+}
+
 int agpt_scene_add_area_light(agpt_scene* s, const float center[3], float radius, const float L[3]) {
     if (!s || !center || !L) return fail(AGPT_ERR_INVALID, "agpt_scene_add_area_light: NULL argument");
     int prim = agpt_scene_add_sphere(s, center, radius, -1);

@@ -394,7 +394,7 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
         dp.type = hp.type;
         dp.material = hp.material;
         dp.arealight = hp.arealight;
-        if (hp.type == AGPT_PRIM_SPHERE) {
+        if (hp.type == AGPT_PRIM_SPHERE || hp.type == AGPT_PRIM_PLANE) {
             const HostSphere& s = spheres[hp.index];
             dp.cx = s.center.x;
             dp.cy = s.center.y;

@@ -139,7 +139,7 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 #define AGPT_REFILL 20
 #define AGPT_RING 128  // entries of the per-wave ring of pre-filtered rays (power of two, >= 64 + 63)
 // per-primitive root record staged in LDS: [2k] = (bmin.xyz | sphere centre.xyz, kind), [2k+1] = (bmax.xyz, root_enc) |
-// (r2, -, -, -); kind 0 = mesh, 1 = sphere, 2 = empty mesh (never hit)
+// (r2, -, -, -) | (half x, half z, -, -); kind 0 = mesh, 1 = sphere, 2 = empty mesh (never hit), 3 = plane
 
 template <bool ANY>
 __global__ void __launch_bounds__(AGPT_BLOCK)
@@ -160,6 +160,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         if (P.type == AGPT_PRIM_SPHERE) {
             a.x = P.cx; a.y = P.cy; a.z = P.cz; a.w = 1.f;
             b.x = P.r2; b.y = 0.f; b.z = 0.f; b.w = 0.f;
+        } else if (P.type == AGPT_PRIM_PLANE) {
+            a.x = P.cx; a.y = P.cy; a.z = P.cz; a.w = 3.f;
+            b.x = P.r; b.y = P.r2; b.z = 0.f; b.w = 0.f;
         } else {
             a.x = P.root_bmin[0]; a.y = P.root_bmin[1]; a.z = P.root_bmin[2]; a.w = P.n_tris > 0 ? 0.f : 2.f;
             b.x = P.root_bmax[0]; b.y = P.root_bmax[1]; b.z = P.root_bmax[2]; b.w = __uint_as_float(P.root_enc);
@@ -223,9 +226,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     for (int k = 0; k < n_prims; ++k) {
                         const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
                         bool h;
-                        if (pa.w == 1.f) {
+                        if (pa.w == 1.f || pa.w == 3.f) {
                             float root;
-                            h = sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, nr, o.w, root);
+                            h = analytic_test(pa.w, V3(pa.x, pa.y, pa.z), pb2.x, pb2.y, nr, o.w, root);
                         } else {
                             float t0x = __builtin_fmaf(pa.x, nr.R.x, nox), t1x = __builtin_fmaf(pb2.x, nr.R.x, nox);
                             float t0y = __builtin_fmaf(pa.y, nr.R.y, noy), t1y = __builtin_fmaf(pb2.y, nr.R.y, noy);
@@ -369,9 +372,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     const int k = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
-                    if (pa.w == 1.f) {
+                    if (pa.w == 1.f || pa.w == 3.f) {
                         float root;
-                        if (sphere_test_c(V3(pa.x, pa.y, pa.z), pb2.x, r, rayt, root)) {
+                        if (analytic_test(pa.w, V3(pa.x, pa.y, pa.z), pb2.x, pb2.y, r, rayt, root)) {
                             if (ANY) {
                                 occluded[pid] = 1u;
                                 active = false;

@@ -20,12 +20,13 @@
 
 #define AGPT_PRIM_MESH 0
 #define AGPT_PRIM_SPHERE 1
+#define AGPT_PRIM_PLANE 2   // intersectable.h:119-157: cx,cy,cz = O, r = HalfSize.x, r2 = HalfSize.y
 #define AGPT_LIGHT_AREA 0
 #define AGPT_LIGHT_UNIFORM_INFINITE 1
 #define AGPT_LIGHT_INFINITE_AREA 2
 
 #define AGPT_HIT_MISS 0xFFFFFFFFu
-#define AGPT_HIT_SPHERE 0x80000000u
+#define AGPT_HIT_SPHERE 0x80000000u   // analytic primitive (sphere or plane): low bits = primitive index
 
 #define AGPT_TRI_FLAG_REJECT 1u     // degenerate triangle: TriangleIntersect returns false after the t test
 #define AGPT_STACK_DEPTH 32         // per-lane traversal stack entries staged in LDS

@@ -401,10 +401,20 @@ __device__ __forceinline__ void surface_from_triangle(const DevScene& sc, uint32
         s.n = faceforward(ng, s.ns);
     }
 }
-// Sphere::Intersect's tail (intersectable.h:183-201): dpdu/dpdv are passed swapped
+// Sphere::Intersect's tail (intersectable.h:183-201): dpdu/dpdv are passed swapped.  Also Plane::Intersect's
+// (intersectable.h:133): SurfaceInteraction(P, uv, -D, dpdu = (0,0,1), dpdv = (1,0,0)).
 __device__ __forceinline__ void surface_from_sphere(const DevScene& sc, int prim, v3 O, v3 D, float t, Surface& s) {
     const DevPrim& P = sc.prims[prim];
     v3 p = O + t * D;
+    if (P.type == AGPT_PRIM_PLANE) {
+        s.prim = prim;
+        s.p = p;
+        s.wo = -D;
+        s.n = normalize(cross(V3(0, 0, 1), V3(1, 0, 0)));
+        s.ns = s.n;
+        s.ss_bsdf = normalize(V3(0, 0, 1));
+        return;
+    }
     v3 pHit = p - V3(P.cx, P.cy, P.cz);
     if (pHit.x == 0 && pHit.y == 0) pHit.x = AGPT_EPSILON * P.r;
     float theta = cr_acosf(tclampf(pHit.z / P.r, -1.f, 1.f));

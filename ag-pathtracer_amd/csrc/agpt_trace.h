@@ -133,7 +133,25 @@ __device__ __forceinline__ bool sphere_test_c(v3 center, float r2, const TraceRa
     root_out = root;
     return true;
 }
+// Plane::Intersect / IntersectP (intersectable.h:123-150): XZ rectangle, accepted for 0 < t < ray.t
+__device__ __forceinline__ bool plane_test_c(v3 O, float hx, float hz, const TraceRay& r, float rayt, float& t_out) {
+    if (r.D.y == 0) return false;
+    float t = (O.y - r.O.y) / r.D.y;
+    if (t <= 0 || t >= rayt) return false;
+    v3 P = r.O + t * r.D;
+    float u = (P.x - O.x) / hx;
+    float v = (P.z - O.z) / hz;
+    if (!(fabsf(u) <= 1 && fabsf(v) <= 1)) return false;
+    t_out = t;
+    return true;
+}
+// analytic primitives: kind 1 = sphere (b.x = r2), kind 3 = plane (b.x, b.y = half size)
+__device__ __forceinline__ bool analytic_test(float kind, v3 a, float bx, float by, const TraceRay& r, float rayt, float& t_out) {
+    if (kind == 1.f) return sphere_test_c(a, bx, r, rayt, t_out);
+    return plane_test_c(a, bx, by, r, rayt, t_out);
+}
 __device__ __forceinline__ bool sphere_test(const DevPrim& P, const TraceRay& r, float rayt, float& root_out) {
+    if (P.type == AGPT_PRIM_PLANE) return plane_test_c(V3(P.cx, P.cy, P.cz), P.r, P.r2, r, rayt, root_out);
     return sphere_test_c(V3(P.cx, P.cy, P.cz), P.r2, r, rayt, root_out);
 }
 
@@ -179,7 +197,7 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
         for (int k = 0; k < nchunk; ++k) {
             const DevPrim& P = sc.prims[base + k];
             bool h;
-            if (P.type == AGPT_PRIM_SPHERE) {
+            if (P.type != AGPT_PRIM_MESH) {
                 float root;
                 h = sphere_test(P, r, rayt, root);
             } else {
@@ -200,7 +218,7 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
                 mask &= mask - 1;
                 const int pi = base + k;
                 const DevPrim& P = sc.prims[pi];
-                if (P.type == AGPT_PRIM_SPHERE) {
+                if (P.type != AGPT_PRIM_MESH) {
                     float root;
                     if (sphere_test(P, r, rayt, root)) {
                         if (ANY) {

@@ -61,6 +61,11 @@ class SceneDesc:
         self.n_prims += 1
         return self.n_prims - 1
 
+    def add_plane(self, o, size, material):
+        self.ops.append(("plane", np.asarray(o, F).copy(), np.asarray(size, F).copy(), int(material)))
+        self.n_prims += 1
+        return self.n_prims - 1
+
     def add_area_light(self, center, radius, L):
         self.ops.append(("area_light", np.asarray(center, F).copy(), float(radius), np.asarray(L, F).copy()))
         self.n_prims += 1
@@ -91,6 +96,8 @@ class SceneDesc:
                 target.add_mesh(op[1], op[2], op[3], op[4], op[5], op[6])
             elif k == "sphere":
                 target.add_sphere(op[1], op[2], op[3])
+            elif k == "plane":
+                target.add_plane(op[1], op[2], op[3])
             elif k == "area_light":
                 target.add_area_light(op[1], op[2], op[3])
             elif k == "infinite_light":

@@ -122,6 +122,8 @@ int agpt_scene_add_mesh(agpt_scene*, const float* vertices, int n_vertices, cons
                         int material, int max_prims_in_node);
 /* scene->primitives.push_back(make_shared<Sphere>(center, r, material)); material -1 = nullptr */
 int agpt_scene_add_sphere(agpt_scene*, const float center[3], float radius, int material);
+/* scene->primitives.push_back(make_shared<Plane>(o, size, material)) (intersectable.h:119-157): XZ rectangle, +Y normal */
+int agpt_scene_add_plane(agpt_scene*, const float o[3], const float size[2], int material);
 /* Scene::addAreaLight(make_shared<Sphere>(center, r, nullptr), L) (scene.h:21-25): returns primitive index */
 int agpt_scene_add_area_light(agpt_scene*, const float center[3], float radius, const float L[3]);
 /* scene->lights.push_back(make_shared<UniformInfiniteLight>(L)) (lights.h:37-51): returns light index */

@@ -104,6 +104,11 @@ struct Sphere {
     float3 center;
     float radius;
 };
+// Plane (intersectable.h:119-157): XZ rectangle with +Y normal, size = full extents
+struct Plane {
+    float3 o;
+    float size_x, size_z;
+};
 struct UniformInfiniteLight {
     float3 L;
 };
@@ -139,6 +144,10 @@ public:
     int primitives_push_back(const Sphere& s, int material) {
         const float c[3] = {s.center.x, s.center.y, s.center.z};
         return check(agpt_scene_add_sphere(h_, c, s.radius, material), "agpt_scene_add_sphere");
+    }
+    int primitives_push_back(const Plane& p, int material) {
+        const float o[3] = {p.o.x, p.o.y, p.o.z}, sz[2] = {p.size_x, p.size_z};
+        return check(agpt_scene_add_plane(h_, o, sz, material), "agpt_scene_add_plane");
     }
     int addAreaLight(const Sphere& s, float3 L) {
         const float c[3] = {s.center.x, s.center.y, s.center.z}, l[3] = {L.x, L.y, L.z};

@@ -65,6 +65,8 @@ int oracle_add_mesh(oracle_scene*, const float* verts, int n_verts, const float*
                     int max_prims_in_node);
 /* Sphere(center, r, material) pushed to Scene::primitives; material -1 = nullptr */
 int oracle_add_sphere(oracle_scene*, const float center[3], float radius, int material);
+/* Plane(o, size, material) pushed to Scene::primitives (intersectable.h:119-157) */
+int oracle_add_plane(oracle_scene*, const float o[3], const float size[2], int material);
 /* Scene::addAreaLight(make_shared<Sphere>(center, r, nullptr), L): returns primitive index */
 int oracle_add_area_light(oracle_scene*, const float center[3], float radius, const float L[3]);
 /* scene.lights.push_back(make_shared<UniformInfiniteLight>(L)) */

@@ -59,6 +59,7 @@ def lib():
     L.oracle_add_material.argtypes = [C.c_void_p, C.c_int, fp, C.c_float, C.c_float]
     L.oracle_add_mesh.argtypes = [C.c_void_p, fp, C.c_int, fp, C.c_int, fp, C.c_int, ip, C.c_int, C.c_int, C.c_int]
     L.oracle_add_sphere.argtypes = [C.c_void_p, fp, C.c_float, C.c_int]
+    L.oracle_add_plane.argtypes = [C.c_void_p, fp, fp, C.c_int]
     L.oracle_add_area_light.argtypes = [C.c_void_p, fp, C.c_float, fp]
     L.oracle_add_uniform_infinite_light.argtypes = [C.c_void_p, fp]
     L.oracle_add_infinite_area_light.argtypes = [C.c_void_p, fp, C.c_int, C.c_int]
@@ -174,6 +175,11 @@ class OracleScene:
     def add_sphere(self, center, radius, material):
         c, p = _f(center)
         return self.L.oracle_add_sphere(self.h, p, float(radius), int(material))
+
+    def add_plane(self, o, size, material):
+        a, pa = _f(o)
+        b, pb = _f(size)
+        return self.L.oracle_add_plane(self.h, pa, pb, int(material))
 
     def add_area_light(self, center, radius, L):
         c, p = _f(center)

@@ -269,8 +269,9 @@ typedef struct {
 } Mesh;
 
 typedef struct { f3 Center; float r, r2; } Sphere;
+typedef struct { f3 O; f2 HalfSize; } Plane; /* intersectable.h:119-157: XZ plane, normal +Y */
 
-enum { PRIM_MESH = 0, PRIM_SPHERE = 1 };
+enum { PRIM_MESH = 0, PRIM_SPHERE = 1, PRIM_PLANE = 2 };
 typedef struct {
     int type;
     int index;     /* into meshes / spheres */
@@ -304,6 +305,7 @@ struct oracle_scene {
     Material* materials; int n_materials;
     Mesh* meshes; int n_meshes;
     Sphere* spheres; int n_spheres;
+    Plane* planes; int n_planes;
     ScenePrim* prims; int n_prims;
     Light* lights; int n_lights;
     Camera cam;
@@ -324,7 +326,7 @@ void oracle_scene_free(oracle_scene* s) {
     }
     for (int i = 0; i < s->n_lights; i++)
         if (s->lights[i].env) { free(s->lights[i].env->pixels); free(s->lights[i].env->func); free(s->lights[i].env->cdf); free(s->lights[i].env); }
-    free(s->materials); free(s->meshes); free(s->spheres); free(s->prims); free(s->lights);
+    free(s->materials); free(s->meshes); free(s->spheres); free(s->planes); free(s->prims); free(s->lights);
     free(s);
 }
 void oracle_set_max_depth(oracle_scene* s, int d) { s->MaxDepth = d; }
@@ -570,6 +572,15 @@ int oracle_add_sphere(oracle_scene* s, const float center[3], float radius, int 
     sp->r = radius; sp->r2 = radius * radius; /* intersectable.h:161-162 */
     ScenePrim* p = PUSH(s->prims, s->n_prims, ScenePrim);
     p->type = PRIM_SPHERE; p->index = s->n_spheres - 1; p->material = material; p->arealight = -1;
+    return s->n_prims - 1;
+}
+/* Plane(o, size, material) pushed to Scene::primitives (intersectable.h:121) */
+int oracle_add_plane(oracle_scene* s, const float o[3], const float size[2], int material) {
+    Plane* pl = PUSH(s->planes, s->n_planes, Plane);
+    pl->O = F3(o[0], o[1], o[2]);
+    pl->HalfSize.x = size[0] / 2; pl->HalfSize.y = size[1] / 2;
+    ScenePrim* p = PUSH(s->prims, s->n_prims, ScenePrim);
+    p->type = PRIM_PLANE; p->index = s->n_planes - 1; p->material = material; p->arealight = -1;
     return s->n_prims - 1;
 }
 int oracle_add_area_light(oracle_scene* s, const float center[3], float radius, const float L[3]) { /* scene.h:21-25 */
@@ -953,6 +964,32 @@ static float sphere_pdf(const Sphere* sp, const SurfaceInteraction* ref, f3 wi) 
     return uniform_cone_pdf(cosThetaMax);
 }
 
+/* Plane::Intersect / IntersectP -- intersectable.h:123-150 */
+static int plane_intersect(const Plane* pl, int shape, Ray* ray, SurfaceInteraction* hit) {
+    if (ray->D.y == 0) return 0;
+    float t = (pl->O.y - ray->O.y) / ray->D.y;
+    if (t <= 0 || t >= ray->t) return 0;
+    f3 P = ray_at(ray, t);
+    float u = (P.x - pl->O.x) / pl->HalfSize.x;
+    float v = (P.z - pl->O.z) / pl->HalfSize.y;
+    if (fabsf(u) <= 1 && fabsf(v) <= 1) { /* fabs(float v) promotes to double: same comparison result */
+        f2 uv; uv.x = (u + 1) * .5f; uv.y = (v + 1) * .5f;
+        si_init(hit, P, uv, f3_neg(ray->D), F3(0, 0, 1), F3(1, 0, 0), shape);
+        ray->t = t;
+        return 1;
+    }
+    return 0;
+}
+static int plane_intersect_p(const Plane* pl, const Ray* ray) {
+    if (ray->D.y == 0) return 0;
+    float t = (pl->O.y - ray->O.y) / ray->D.y;
+    if (t <= 0 || t >= ray->t) return 0;
+    f3 P = ray_at(ray, t);
+    float u = (P.x - pl->O.x) / pl->HalfSize.x;
+    float v = (P.z - pl->O.z) / pl->HalfSize.y;
+    return (fabsf(u) <= 1 && fabsf(v) <= 1);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Scene::Intersect / IntersectP -- scene.h:5-19
  * ---------------------------------------------------------------------------------------------- */
@@ -961,8 +998,9 @@ static int scene_intersect(const oracle_scene* s, Ray* ray, SurfaceInteraction* 
     int found = 0;
     for (int i = 0; i < s->n_prims; i++) {
         const ScenePrim* p = &s->prims[i];
-        int h = (p->type == PRIM_MESH) ? mesh_intersect(&s->meshes[p->index], i, ray, hit, c)
-                                       : sphere_intersect(&s->spheres[p->index], i, ray, hit);
+        int h = (p->type == PRIM_MESH)    ? mesh_intersect(&s->meshes[p->index], i, ray, hit, c)
+                : (p->type == PRIM_SPHERE) ? sphere_intersect(&s->spheres[p->index], i, ray, hit)
+                                           : plane_intersect(&s->planes[p->index], i, ray, hit);
         if (h) found = 1;
     }
     return found;
@@ -971,8 +1009,9 @@ static int scene_intersect_p(const oracle_scene* s, const Ray* ray, octx* c) {
     c->st.anyhit_rays++;
     for (int i = 0; i < s->n_prims; i++) {
         const ScenePrim* p = &s->prims[i];
-        int h = (p->type == PRIM_MESH) ? mesh_intersect_p(&s->meshes[p->index], ray, c)
-                                       : sphere_intersect_p(&s->spheres[p->index], ray);
+        int h = (p->type == PRIM_MESH)    ? mesh_intersect_p(&s->meshes[p->index], ray, c)
+                : (p->type == PRIM_SPHERE) ? sphere_intersect_p(&s->spheres[p->index], ray)
+                                           : plane_intersect_p(&s->planes[p->index], ray);
         if (h) return 1;
     }
     return 0;

@@ -36,6 +36,10 @@ def scene_bounds(desc):
         elif op[0] in ("sphere", "area_light"):
             lo = np.minimum(lo, op[1] - op[2])
             hi = np.maximum(hi, op[1] + op[2])
+        elif op[0] == "plane":
+            half = np.array([op[2][0] / 2, 0, op[2][1] / 2])
+            lo = np.minimum(lo, op[1] - half)
+            hi = np.maximum(hi, op[1] + half)
     return lo, hi
 
 

@@ -125,3 +125,19 @@ def test_generic_kernel_forced(monkeypatch):
     s.close()
     ctx.close()
     assert fast.tobytes() == gen.tobytes()
+
+
+def test_plane_primitive():
+    """Plane (intersectable.h:119-157; unused by the reference's scenes): closest/any-hit records and a rendered image."""
+    from test_gpu_render import compare
+    d = ag.scenes.scene_c1()
+    m = d.add_material(ag.MAT_DISNEY, [.8, .3, .2], .4, 0.)
+    d.add_plane([0.5, -0.5, -1.0], [3.0, 2.0], m)
+    rays = random_rays(d, 150000, seed=21)
+    # rays parallel to the plane (D.y == 0) and rays grazing its edges
+    extra = np.zeros(4, ag.RAY_DTYPE)
+    extra["o"] = [[0.5, -0.5, -6], [0.5, 3, -1], [2.0, 3, -1], [0.5, -3, 0.0]]
+    extra["d"] = [[0, 0, 1], [0, -1, 0], [0, -1, 0], [0, 1, 0]]
+    extra["tmax"] = 3.402823466e+38
+    check_closest(d, np.concatenate([rays, extra]))
+    compare(d, 96, 96, 2)
