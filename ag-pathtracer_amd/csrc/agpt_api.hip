@@ -599,8 +599,20 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         return fail(AGPT_ERR_INVALID, "agpt_render: bad tile / film / sample range");
     agpt_ctx* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    const uint32_t NP = (uint32_t)rp->w * (uint32_t)rp->h;
-    int S = rp->samples_per_batch > 0 ? rp->samples_per_batch : (int)std::max<uint64_t>(1, (8ull << 20) / NP);
+    uint32_t rows = (uint32_t)rp->h;
+    if (rp->interleave_block > 0) {
+        if (rp->interleave_world < 1 || rp->interleave_rank < 0 || rp->interleave_rank >= rp->interleave_world || rp->x0 != 0 ||
+            rp->y0 != 0 || rp->w != rp->width || rp->h != rp->height)
+            return fail(AGPT_ERR_INVALID, "agpt_render: row interleave needs the whole film as tile and 0 <= rank < world");
+        rows = 0;
+        for (int k = rp->interleave_rank, y = k * rp->interleave_block; y < rp->height;
+             k += rp->interleave_world, y = k * rp->interleave_block)
+            rows += (uint32_t)std::min(rp->interleave_block, rp->height - y);
+        if (rows == 0) return AGPT_OK;
+    }
+    const uint32_t NP = (uint32_t)rp->w * rows;
+    // default batch: up to 128 Mi paths (27 GB of path state -- MI355X has 288 GB); fewer, larger wavefront launches
+    int S = rp->samples_per_batch > 0 ? rp->samples_per_batch : (int)std::max<uint64_t>(1, (128ull << 20) / NP);
     S = std::min(S, std::max(1, rp->spp_count));
     if ((uint64_t)NP * (uint64_t)S > 0x7FFFFFFFull) return fail(AGPT_ERR_LIMIT, "agpt_render: batch too large");
     int rc = ensure_pool(c, (size_t)NP * S);
@@ -632,6 +644,7 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         rcn.s0 = s0; rcn.S = std::min(S, rp->spp_begin + rp->spp_count - s0);
         rcn.seed_base = rp->seed_base; rcn.max_depth = rp->max_depth;
         rcn.accum_pitch = rp->accum_pitch; rcn.accum_row0 = rp->accum_row0; rcn.NP = NP;
+        rcn.il_block = rp->interleave_block; rcn.il_world = rp->interleave_world; rcn.il_rank = rp->interleave_rank;
         const uint32_t total = NP * (uint32_t)rcn.S;
         int cur = 0;
         hipLaunchKernelGGL(k_generate, dim3((total + AGPT_BLOCK - 1) / AGPT_BLOCK), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb,

@@ -51,8 +51,25 @@ struct RenderConsts {
     uint32_t seed_base;
     int32_t max_depth;
     int32_t accum_pitch, accum_row0;
-    uint32_t NP;              // w*h
+    uint32_t NP;              // pixels of the tile this call renders (w * rows)
+    int32_t il_block, il_world, il_rank;  // row-block interleave (il_block == 0: off)
 };
+
+// local pixel index -> film pixel (x, y) and the accumulator element it adds into
+__device__ __forceinline__ void pixel_of(const RenderConsts& rc, uint32_t p, int& x, int& y, size_t& accum_index) {
+    const uint32_t row = p / (uint32_t)rc.w;
+    x = rc.x0 + (int)(p - row * (uint32_t)rc.w);
+    if (rc.il_block == 0) {
+        y = rc.y0 + (int)row;
+        accum_index = (size_t)((rc.H - 1 - y) - rc.accum_row0) * (size_t)rc.accum_pitch + (size_t)x;
+    } else {
+        const int j = (int)row / rc.il_block, within = (int)row % rc.il_block;
+        const int yb = (j * rc.il_world + rc.il_rank) * rc.il_block;
+        const int hb = min(rc.il_block, rc.H - yb);
+        y = yb + within;
+        accum_index = (size_t)(j * rc.il_block + (hb - 1 - within)) * (size_t)rc.accum_pitch + (size_t)x;
+    }
+}
 
 struct DevCounters {
     unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples, roots;
@@ -455,7 +472,9 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
     uint32_t total = rc.NP * (uint32_t)rc.S;
     if (i >= total) return;
     uint32_t sl = i / rc.NP, p = i - sl * rc.NP;
-    int x = rc.x0 + (int)(p % (uint32_t)rc.w), y = rc.y0 + (int)(p / (uint32_t)rc.w);
+    int x, y;
+    size_t unused_index;
+    pixel_of(rc, p, x, y, unused_index);
     uint32_t rng = sample_seed((uint32_t)(y * rc.W + x), (uint32_t)(rc.W * rc.H), (uint32_t)(rc.s0 + (int)sl), rc.seed_base);
     float px = x + rng_float(rng);
     float py = y + rng_float(rng);
@@ -816,8 +835,9 @@ __global__ void __launch_bounds__(AGPT_BLOCK)
 k_accumulate(RenderConsts rc, PathBuffers pb, float4* __restrict__ accum, DevCounters* __restrict__ counters) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= rc.NP) return;
-    int x = rc.x0 + (int)(p % (uint32_t)rc.w), y = rc.y0 + (int)(p / (uint32_t)rc.w);
-    size_t ai = (size_t)((rc.H - 1 - y) - rc.accum_row0) * (size_t)rc.accum_pitch + (size_t)x;
+    int x, y;
+    size_t ai;
+    pixel_of(rc, p, x, y, ai);
     float4 a = accum[ai];
     uint32_t bad = 0;
     for (int s = 0; s < rc.S; s++) {

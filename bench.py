@@ -135,18 +135,16 @@ def main():
 
     rows = tiles.max_local_rows(H, world)
     local = torch.zeros((rows, W, 4), dtype=torch.float32, device=dev)
-    blocks = tiles.row_blocks(H, rank, world)
-    if world == 1:
-        blocks = [(0, H, 0)]  # one call covers the film
+    # one agpt_render call per step and rank: the whole film at N = 1, this rank's interleaved 8-row blocks otherwise
+    interleave = None if world == 1 else (tiles.BLOCK_ROWS, world, rank)
 
     def step(timing):
         local.zero_()
         tot = dict(closest=0, anyhit=0, trace_ms=0.0, ext_ms=0.0, mis_ms=0.0, shadow_ms=0.0, total_ms=0.0, launches=0,
                    iterations=0)
-        for (y0, h, off) in blocks:
-            st = pt.render(scene, W, H, spp, local.data_ptr(), tile=(0, y0, W, h), accum_pitch=W,
-                           accum_row0=tiles.block_accum_row0(H, y0, h, off), samples_per_batch=args.samples_per_batch,
-                           timing=timing)
+        for _ in (0,):
+            st = pt.render(scene, W, H, spp, local.data_ptr(), accum_pitch=W, samples_per_batch=args.samples_per_batch,
+                           timing=timing, interleave=interleave)
             tot["closest"] += st.closest_rays
             tot["anyhit"] += st.anyhit_rays
             tot["trace_ms"] += st.trace_ms
@@ -195,9 +193,7 @@ def main():
     if rank == 0:
         # instrumented pass outside the timed region: deterministic per-scene work counters for the roofline
         # (interior child-pair fetches, triangle tests, root-box tests of the SAME rays), on a 1-spp sample
-        y0, h, off = blocks[0]
-        cst = pt.render(scene, W, H, min(spp, 2), local.data_ptr(), tile=(0, y0, W, h), accum_pitch=W,
-                        accum_row0=tiles.block_accum_row0(H, y0, h, off), counters=True)
+        cst = pt.render(scene, W, H, min(spp, 2), local.data_ptr(), accum_pitch=W, counters=True, interleave=interleave)
         crays = float(cst.rays)
         bytes_per_ray = algorithmic_bytes(cst.closest_rays, cst.anyhit_rays, cst.root_tests, cst.interior_visits,
                                           cst.tri_tests) / crays

@@ -98,6 +98,11 @@ typedef struct {
     int32_t samples_per_batch;    /* 0 = library default */
     int32_t enable_counters;      /* 1 = also count interior visits / triangle tests (slower) */
     int32_t enable_timing;        /* 1 = bracket every trace launch with HIP events on the launch stream */
+    /* multi-GPU row interleave (0 = off): of the film rows, cut into blocks of interleave_block rows, render only the
+     * blocks k with k % interleave_world == interleave_rank (the tile must then be the whole film: x0=y0=0, w=W, h=H).
+     * accum is the rank's COMPACT buffer: block j of this rank occupies rows [j*block, j*block+h_j), flipped inside the
+     * block like Accumulator::AddSample; accum_row0 is ignored. */
+    int32_t interleave_block, interleave_world, interleave_rank;
 } agpt_render_params;
 
 const char* agpt_last_error(void);

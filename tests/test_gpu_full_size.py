@@ -60,8 +60,18 @@ def test_c3_full_scene_1080p_tile_vs_oracle_and_invariances():
         for (y0, h, off) in tiles.row_blocks(H, r, world):
             pt.render(g, W, H, spp, ptr, tile=(0, y0, W, h), accum_row0=tiles.block_accum_row0(H, y0, h, off), want_stats=False)
         bufs.append(ctx.download(ptr, (H, W, 4))[:rows].copy())
-    ctx.free(ptr)
     assert tiles.deinterleave(bufs, W, H, world).tobytes() == full.tobytes()
+    # (b4) the same split through the native row interleave of agpt_render (one call per rank, what bench.py uses)
+    for world in (2, 8):
+        bufs = []
+        for r in range(world):
+            rows = tiles.max_local_rows(H, world)
+            ctx.memset(ptr, 0, W * H * 16)
+            st_r = pt.render(g, W, H, spp, ptr, interleave=(tiles.BLOCK_ROWS, world, r))
+            assert st_r.samples == W * tiles.local_rows(H, r, world) * spp
+            bufs.append(ctx.download(ptr, (H, W, 4))[:rows].copy())
+        assert tiles.deinterleave(bufs, W, H, world).tobytes() == full.tobytes()
+    ctx.free(ptr)
     g.close()
 
 
