@@ -73,6 +73,14 @@ def gather_to_rank0(local_accum, W, H, rank, world, block_rows=BLOCK_ROWS):
         return deinterleave([local_accum], W, H, 1, block_rows)
     # dist.gather on the nccl backend is RCCL grouped send/recv: every peer's buffer (<= 17 MB at 4K) travels its own
     # direct xGMI link to rank 0, so the exchange is not ring-bound.
+    if dist.get_backend() == "gloo" and local_accum.is_cuda:
+        # rehearsal path (several ranks on one GPU): gloo gathers through host memory
+        host = local_accum.cpu()
+        bufs = [host.new_zeros(host.shape) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, bufs, dst=0)
+        if rank != 0:
+            return None
+        return deinterleave([b.to(local_accum.device) for b in bufs], W, H, world, block_rows)
     bufs = [local_accum.new_zeros(local_accum.shape) for _ in range(world)] if rank == 0 else None
     dist.gather(local_accum, bufs, dst=0)
     if rank != 0:

@@ -119,17 +119,23 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; AGPT_BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks sharing one GPU
+    backend = os.environ.get("AGPT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     W, H, MAXD = args.width, args.height, 5
     spp = args.spp * world
     desc = ag.scenes.scene_c3(scale=args.scene_scale, aspect=W / float(H))
-    ctx = ag.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    ctx = ag.Context(dev_index, stream=torch.cuda.current_stream().cuda_stream)
     scene = desc.instantiate(ag.Scene(ctx))
     pt = ag.PathTracer(MAXD)
 
