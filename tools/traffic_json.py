@@ -37,7 +37,7 @@ for k in sorted(agg):
               "counters": {kk: vv for kk, vv in c.items()}}
     tot_bytes += rd + wr
     tot_launch += n
-json.dump({"workload": "bench.py --spp 4 (one 8.3 M-path batch: launch sizes equal the 64-spp workload's)",
+json.dump({"workload": "bench.py --steps 1 --warmup 0 (the full 1080p/64spp step, one 132.7 M-path batch)",
            "kernel": "k_trace_fast<closest> + k_trace_fast<any>", "hbm_bytes_per_launch": tot_bytes / max(1, tot_launch),
            "launches": tot_launch, "per_kernel": res}, open(out, "w"), indent=1)
 print(json.dumps({"hbm_bytes_per_launch": tot_bytes / max(1, tot_launch), "launches": tot_launch}))
