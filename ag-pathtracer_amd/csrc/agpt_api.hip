@@ -61,7 +61,7 @@ struct agpt_ctx {
     size_t pool_paths = 0;
     DevBuf<float4> ext_o, ext_d, sh_o, sh_d, mis_o, mis_d, beta4, L4, fac4, c1, c2;
     DevBuf<DevHit> hit, mis_hit;
-    DevBuf<uint32_t> occluded;
+    DevBuf<uint32_t> occluded, mis_ok;
     DevBuf<uint32_t> q[2][4];
     DevBuf<uint32_t> qcounts;   // 2 x 4 queue lengths
     DevBuf<uint32_t> work;      // work-queue heads of the persistent trace launches
@@ -70,6 +70,7 @@ struct agpt_ctx {
     int blocks_per_cu = 4;       // AGPT_BLOCKS_PER_CU
     int refill = AGPT_REFILL;    // AGPT_REFILL: idle lanes that trigger an in-flight refill
     int vote[3] = {1, 1, 1};     // AGPT_VOTE=a,b,c: phase weights of the trace kernel's vote scheduler (tuning)
+    bool mis_closest = false;    // AGPT_MIS_CLOSEST=1: trace MIS rays as full closest-hit queries (A/B, tests)
     bool force_generic = false;  // AGPT_FORCE_GENERIC=1: always use the generic k_trace (tests)
     // per-launch HIP-event timing of the trace kernels (agpt_render_params::enable_timing)
     std::vector<hipEvent_t> tev;
@@ -109,12 +110,18 @@ static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
 
 static int trace_grid(const agpt_ctx* c) { return c->num_cus * c->blocks_per_cu; }
 
-template <bool ANY>
+static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, bool count) {
+    return !count && sc.n_prims <= 64 && !c->force_generic;
+}
+
+// MODE 0 closest, 1 any-hit, 2 MIS query (production kernel only; the generic kernel traces MIS rays as closest hits)
+template <int MODE>
 static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
                          uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, bool count) {
+    constexpr bool ANY = MODE == 1;
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
-    if (!count && sc.n_prims <= 64 && !c->force_generic)
-        hipLaunchKernelGGL((k_trace_fast<ANY>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
+    if (use_fast_trace(c, sc, count))
+        hipLaunchKernelGGL((k_trace_fast<MODE>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
                            hits, occ, c->counters.p, c->refill, c->vote[0], c->vote[1], c->vote[2]);
     else if (count)
         hipLaunchKernelGGL((k_trace<ANY, true>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
@@ -133,7 +140,7 @@ static hipEvent_t next_event(agpt_ctx* c) {
     return c->tev[c->tev_used++];
 }
 
-template <bool ANY>
+template <int MODE>
 static void launch_trace_timed(agpt_ctx* c, bool timing, int kind, const DevScene& sc, const uint32_t* queue,
                                const uint32_t* count_ptr, uint32_t count_imm, uint32_t* work_head, const float4* ro,
                                const float4* rd, DevHit* hits, uint32_t* occ, bool count) {
@@ -141,7 +148,7 @@ static void launch_trace_timed(agpt_ctx* c, bool timing, int kind, const DevScen
         (void)hipEventRecord(next_event(c), c->stream);
         c->tev_kind.push_back(kind);
     }
-    launch_trace<ANY>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, count);
+    launch_trace<MODE>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, count);
     if (timing) (void)hipEventRecord(next_event(c), c->stream);
 }
 
@@ -167,6 +174,7 @@ int agpt_init(int device, agpt_ctx** out) {
     HIP_TRY(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(uint32_t)));
     const char* fg = getenv("AGPT_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    if (const char* mc = getenv("AGPT_MIS_CLOSEST")) c->mis_closest = mc[0] == '1';
     if (const char* bp = getenv("AGPT_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(bp));
     if (const char* rf = getenv("AGPT_REFILL")) c->refill = std::min(64, std::max(1, atoi(rf)));
     if (const char* vt = getenv("AGPT_VOTE")) sscanf(vt, "%d:%d:%d", &c->vote[0], &c->vote[1], &c->vote[2]);
@@ -190,6 +198,7 @@ void agpt_destroy(agpt_ctx* c) {
     c->hit.release();
     c->mis_hit.release();
     c->occluded.release();
+    c->mis_ok.release();
     for (int i = 0; i < 2; i++)
         for (int j = 0; j < 4; j++) c->q[i][j].release();
     c->qcounts.release();
@@ -523,6 +532,7 @@ static int ensure_pool(agpt_ctx* c, size_t paths) {
     if ((rc = c->hit.ensure(paths))) return rc;
     if ((rc = c->mis_hit.ensure(paths))) return rc;
     if ((rc = c->occluded.ensure(paths))) return rc;
+    if ((rc = c->mis_ok.ensure(paths))) return rc;
     for (int i = 0; i < 2; i++)
         for (int j = 0; j < 4; j++)
             if ((rc = c->q[i][j].ensure(paths))) return rc;
@@ -563,10 +573,10 @@ int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* o
     hipLaunchKernelGGL(k_prepare_rays, dim3(blocks), dim3(AGPT_BLOCK), 0, c->stream, d_rays, n, c->ext_o.p, c->ext_d.p);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (any_hit)
-        launch_trace<true>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
+        launch_trace<1>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
                            stats != nullptr);
     else
-        launch_trace<false>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
+        launch_trace<0>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
                             stats != nullptr);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     hipLaunchKernelGGL(k_export_hits, dim3(blocks), dim3(AGPT_BLOCK), 0, c->stream, s->dev, c->hit.p, c->occluded.p, n, any_hit,
@@ -622,7 +632,7 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     PathBuffers pb;
     pb.ext_o = c->ext_o.p; pb.ext_d = c->ext_d.p; pb.sh_o = c->sh_o.p; pb.sh_d = c->sh_d.p;
     pb.mis_o = c->mis_o.p; pb.mis_d = c->mis_d.p; pb.hit = c->hit.p; pb.mis_hit = c->mis_hit.p;
-    pb.occluded = c->occluded.p; pb.beta4 = c->beta4.p; pb.L4 = c->L4.p; pb.fac4 = c->fac4.p;
+    pb.occluded = c->occluded.p; pb.mis_ok = c->mis_ok.p; pb.beta4 = c->beta4.p; pb.L4 = c->L4.p; pb.fac4 = c->fac4.p;
     pb.c1 = c->c1.p; pb.c2 = c->c2.p;
     Queues q[2];
     for (int i = 0; i < 2; i++) {
@@ -630,6 +640,7 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         q[i].counts = c->qcounts.p + 4 * AGPT_QSTRIDE * i;
     }
     const bool count = rp->enable_counters != 0;
+    const bool mis_mode = use_fast_trace(c, s->dev, count) && !c->mis_closest;
     const bool timing = rp->enable_timing != 0 && stats != nullptr;
     c->tev_used = 0;
     c->tev_kind.clear();
@@ -644,6 +655,7 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         rcn.s0 = s0; rcn.S = std::min(S, rp->spp_begin + rp->spp_count - s0);
         rcn.seed_base = rp->seed_base; rcn.max_depth = rp->max_depth;
         rcn.accum_pitch = rp->accum_pitch; rcn.accum_row0 = rp->accum_row0; rcn.NP = NP;
+        rcn.mis_mode = mis_mode ? 1 : 0;
         rcn.il_block = rp->interleave_block; rcn.il_world = rp->interleave_world; rcn.il_rank = rp->interleave_rank;
         const uint32_t total = NP * (uint32_t)rcn.S;
         int cur = 0;
@@ -662,9 +674,12 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
             const int nxt = cur ^ 1;
             HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
             HIP_TRY(hipMemsetAsync(c->work.p, 0, 96 * sizeof(uint32_t), c->stream));
-            launch_trace_timed<false>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
-            launch_trace_timed<false>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + 32, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
-            launch_trace_timed<true>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 64, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+            launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
+            if (mis_mode)
+                launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + 32, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
+            else
+                launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + 32, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
+            launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 64, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
             hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
             cur = nxt;
             iterations++;

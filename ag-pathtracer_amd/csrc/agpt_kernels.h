@@ -32,6 +32,7 @@ struct PathBuffers {
     float4 *mis_o, *mis_d;        // MIS ray
     DevHit *hit, *mis_hit;
     uint32_t* occluded;
+    uint32_t* mis_ok;             // MIS-query result of the production kernel (mis_mode 1)
     float4* beta4;                // beta.xyz, flags
     float4* L4;                   // L.xyz, rng state
     float4* fac4;                 // f*|wi.ns|/pdf of the sampled continuation, chosen light index
@@ -53,6 +54,7 @@ struct RenderConsts {
     int32_t accum_pitch, accum_row0;
     uint32_t NP;              // pixels of the tile this call renders (w * rows)
     int32_t il_block, il_world, il_rank;  // row-block interleave (il_block == 0: off)
+    int32_t mis_mode;                     // 0: MIS rays traced as closest-hit (mis_hit), 1: as MIS queries (mis_ok)
 };
 
 // local pixel index -> film pixel (x, y) and the accumulator element it adds into
@@ -158,12 +160,25 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 // per-primitive root record staged in LDS: [2k] = (bmin.xyz | sphere centre.xyz, kind), [2k+1] = (bmax.xyz, root_enc) |
 // (r2, -, -, -) | (half x, half z, -, -); kind 0 = mesh, 1 = sphere, 2 = empty mesh (never hit), 3 = plane
 
-template <bool ANY>
+// MODE 0: Scene::Intersect (closest hit).  MODE 1: Scene::IntersectP (any hit, shadow rays).
+// MODE 2: the MIS query of EstimateDirect's BSDF-sampling leg (integrator.h:76-88).  The reference runs a full
+// Scene::Intersect there but only uses "is the closest hit the sampled light's shape" (area light) or "did the ray
+// escape" (infinite light).  That boolean is answered exactly by an early-exit traversal:
+//   * infinite light: ok iff nothing is hit (any-hit);
+//   * area light with sphere S (primitive index kS): let t_s be S's accepted root for this ray.  If S is missed the
+//     answer is no; else ok iff no other primitive yields a hit the reference would have kept in front of S:
+//     triangles and planes need t < t_s (their tests are strict on both list sides), another sphere P blocks iff
+//     root_P < t_s when P precedes S in Scene::primitives and root_P <= t_s when it follows (Sphere::Intersect accepts
+//     root <= ray.t, so a tie goes to the later primitive); degenerate triangles never block (quirk 11).
+// Every MIS ray is still traced through the BVH; it stops at the first blocker instead of finishing a closest-hit search.
+template <int MODE>
 __global__ void __launch_bounds__(AGPT_BLOCK)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
              DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters,
              int refill, int vote_a, int vote_b, int vote_c) {
+    constexpr bool ANY = MODE != 0;
+    constexpr bool MIS = MODE == 2;
     __shared__ uint32_t s_stack[AGPT_STACK_DEPTH * AGPT_BLOCK];
     __shared__ float4 s_prim[2 * 64];
     uint32_t* stack = s_stack + threadIdx.x;
@@ -214,6 +229,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     uint32_t* ring_pid = s_ring_pid[threadIdx.x >> 6];
     unsigned long long* ring_mask = s_ring_mask[threadIdx.x >> 6];
     uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, monotonically increasing
+    int mis_skip = -1;        // MODE 2: primitive index of the sampled area light's sphere (never a blocker itself)
+    bool mis_reach = true;    // MODE 2: infinite light, or the ray reaches the light's sphere
     bool any_slow = false;                  // wave-uniform: some active lane's ray needs the true-division slab test
 
     for (;;) {
@@ -231,8 +248,19 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                 const uint32_t n_new = base < count ? (count - base < 64u ? count - base : 64u) : 0u;
                 if ((uint32_t)lane < n_new) {
                     const uint32_t npid = queue ? queue[base + lane] : base + lane;
-                    const float4 o = ray_o[npid], d = ray_d[npid];
+                    float4 o = ray_o[npid];
+                    const float4 d = ray_d[npid];
                     const TraceRay nr = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
+                    unsigned long long skip_bit = 0;
+                    if (MIS) {
+                        const DevLight& lt = sc.lights[__float_as_uint(d.w)];
+                        if (lt.type == AGPT_LIGHT_AREA) {
+                            const float4 sa = s_prim[2 * lt.shape], sb = s_prim[2 * lt.shape + 1];
+                            float ts;
+                            if (sphere_test_c(V3(sa.x, sa.y, sa.z), sb.x, nr, o.w, ts)) o.w = ts;
+                            skip_bit = 1ull << lt.shape;
+                        }
+                    }
                     // phase A: conservative per-primitive filter at the initial t.  t ~ fma(b, R, -RN(O*R)) differs from
                     // the exact quotient (b-O)/D by at most 2^-23 |t| + 2^-24 |O*R| (R = RN(1/D), one rounding of O*R, one
                     // of the fma); rejecting only when tmax*(1+2e-6) + 2E < tmin with E = 2^-22 max|O*R| can therefore
@@ -258,7 +286,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                     const uint32_t slot = (ring_tail + (uint32_t)lane) & (AGPT_RING - 1);
                     ring_pid[slot] = npid;
-                    ring_mask[slot] = nr.fast ? m : all_prims;
+                    ring_mask[slot] = (nr.fast ? m : all_prims) & ~skip_bit;
                 }
                 ring_tail += n_new;
             }
@@ -277,6 +305,18 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     float4 o = ray_o[pid], d = ray_d[pid];
                     r = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                     rayt = o.w;
+                    if (MIS) {
+                        mis_skip = -1;
+                        mis_reach = true;
+                        const DevLight& lt = sc.lights[__float_as_uint(d.w)];
+                        if (lt.type == AGPT_LIGHT_AREA) {
+                            const float4 sa = s_prim[2 * lt.shape], sb = s_prim[2 * lt.shape + 1];
+                            float ts;
+                            mis_skip = lt.shape;
+                            mis_reach = sphere_test_c(V3(sa.x, sa.y, sa.z), sb.x, r, rayt, ts);
+                            if (mis_reach) rayt = ts;
+                        }
+                    }
                     hid = AGPT_HIT_MISS;
                     hb1 = 0.f;
                     hb2 = 0.f;
@@ -349,11 +389,15 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
                         float t, b1, b2;
                         if (tri_test(V3(q0.x, q0.y, q0.z), V3(q1.x, q1.y, q1.z), V3(q2.x, q2.y, q2.z), r, rayt, t, b1, b2)) {
-                            if (ANY) {
+                            if (MIS) {
+                                if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
+                                    done = true;
+                                    break;
+                                }
+                            } else if (ANY) {
                                 done = true;
                                 break;
-                            }
-                            if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
+                            } else if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
                                 rayt = t;
                                 hid = __float_as_uint(q0.w);
                                 hb1 = b1;
@@ -362,7 +406,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         }
                     }
                     if (ANY && done) {
-                        occluded[pid] = 1u;
+                        occluded[pid] = MIS ? 0u : 1u;   // MODE 2 writes "ok" (1 = add the BSDF-leg contribution)
                         active = false;
                     } else if (sp == 0) {
                         in_mesh = false;
@@ -374,7 +418,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             } else if (wantA) {
                 // next primitive of this lane's mask (list order), or retire
                 if (mask == 0) {
-                    if (ANY)
+                    if (MIS)
+                        occluded[pid] = mis_reach ? 1u : 0u;
+                    else if (ANY)
                         occluded[pid] = 0u;
                     else {
                         DevHit h;
@@ -392,7 +438,14 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     if (pa.w == 1.f || pa.w == 3.f) {
                         float root;
                         if (analytic_test(pa.w, V3(pa.x, pa.y, pa.z), pb2.x, pb2.y, r, rayt, root)) {
-                            if (ANY) {
+                            if (MIS) {
+                                // a sphere listed before the light's sphere only wins a strict comparison (see above)
+                                const bool tie_loses = pa.w == 1.f && mis_skip >= 0 && mis_reach && k < mis_skip && root == rayt;
+                                if (!tie_loses) {
+                                    occluded[pid] = 0u;
+                                    active = false;
+                                }
+                            } else if (ANY) {
                                 occluded[pid] = 1u;
                                 active = false;
                             } else {
@@ -418,10 +471,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         }
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (ANY)
+        if (MODE == 1)
             atomicAdd(&counters->anyhit_rays, (unsigned long long)count);
         else
-            atomicAdd(&counters->closest_rays, (unsigned long long)count);
+            atomicAdd(&counters->closest_rays, (unsigned long long)count);   // MIS queries are Scene::Intersect calls
     }
 }
 
@@ -544,9 +597,10 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
         }
         if (flags & PF_PEND_C2) {
             uint32_t light = __float_as_uint(f4.w);
-            uint32_t hid = pb.mis_hit[pid].id;
             bool add;
-            if (hid != AGPT_HIT_MISS) {  // integrator.h:82-85: hit shape's area light must be the sampled light
+            if (rc.mis_mode) {
+                add = pb.mis_ok[pid] != 0;
+            } else if (uint32_t hid = pb.mis_hit[pid].id; hid != AGPT_HIT_MISS) {  // integrator.h:82-85: hit shape's area light must be the sampled light
                 int hp = (hid & AGPT_HIT_SPHERE) ? (int)(hid & 0x7FFFFFFFu)
                                                  : (int)__float_as_uint(sc.tri_shade[4 * (size_t)hid + 3].w);
                 add = sc.prims[hp].arealight == (int)light;
@@ -721,7 +775,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                             float4 c4, mo4, md4;
                             c4.x = c2.x; c4.y = c2.y; c4.z = c2.z; c4.w = 0.f;
                             mo4.x = mO.x; mo4.y = mO.y; mo4.z = mO.z; mo4.w = AGPT_FLT_MAX;
-                            md4.x = mD.x; md4.y = mD.y; md4.z = mD.z; md4.w = 0.f;
+                            md4.x = mD.x; md4.y = mD.y; md4.z = mD.z; md4.w = __uint_as_float((uint32_t)numLight);
                             pb.c2[pid] = c4;
                             pb.mis_o[pid] = mo4;
                             pb.mis_d[pid] = md4;
