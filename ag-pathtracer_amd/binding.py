@@ -78,7 +78,12 @@ def lib():
     if _LIB is not None:
         return _LIB
     path = _build.LIB
-    if not os.path.exists(path) or (os.path.exists(_build.CSRC) and _build.needs_build()):
+    variant = os.environ.get("AGPT_LIB_VARIANT")   # developer A/B builds (tools/build_variant.py), never set in production
+    if variant:
+        path = os.path.join(os.path.dirname(path), "libagpt_hip_%s.so" % variant)
+        if not os.path.exists(path):
+            raise AgptError("AGPT_LIB_VARIANT=%s: %s does not exist" % (variant, path))
+    elif not os.path.exists(path) or (os.path.exists(_build.CSRC) and _build.needs_build()):
         try:
             _build.build()
         except Exception as e:  # noqa: BLE001

@@ -10,7 +10,10 @@ HEADERS = ["agpt_math.h", "agpt_scene.h", "agpt_trace.h", "agpt_shade.h", "agpt_
            os.path.join("..", "..", "include", "agpt.h")]
 # -ffp-contract=off + no fast-math: every fp32 op rounds on its own, exactly as written (parity with the oracle);
 # explicit __builtin_fmaf calls (Markstein division in agpt_trace.h) stay fused.
+# -fno-slp-vectorize: the SLP pass packs adjacent f32 adds/muls into v_pk_*_f32, which on gfx950 cost more than the two
+# scalar ops they replace (measured: trace -1 %, shade -2.5 % with the pass off).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 

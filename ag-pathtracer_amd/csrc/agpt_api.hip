@@ -111,7 +111,7 @@ static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
 static int trace_grid(const agpt_ctx* c) { return c->num_cus * c->blocks_per_cu; }
 
 static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, bool count) {
-    return !count && sc.n_prims <= 64 && !c->force_generic;
+    return !count && sc.n_prims <= 64 && sc.max_depth <= AGPT_STACK_DEPTH && !c->force_generic;
 }
 
 // MODE 0 closest, 1 any-hit, 2 MIS query (production kernel only; the generic kernel traces MIS rays as closest hits)
@@ -123,12 +123,20 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     if (use_fast_trace(c, sc, count))
         hipLaunchKernelGGL((k_trace_fast<MODE>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
                            hits, occ, c->counters.p, c->refill, c->vote[0], c->vote[1], c->vote[2]);
-    else if (count)
-        hipLaunchKernelGGL((k_trace<ANY, true>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
-                           hits, occ, c->counters.p);
+    else if (sc.max_depth > AGPT_STACK_DEPTH) {
+        dim3 grid_deep(c->num_cus * 2);
+        if (count)
+            hipLaunchKernelGGL((k_trace<ANY, true, AGPT_STACK_DEPTH_MAX>), grid_deep, block, 0, c->stream, sc, queue, count_ptr,
+                               count_imm, work_head, ro, rd, hits, occ, c->counters.p);
+        else
+            hipLaunchKernelGGL((k_trace<ANY, false, AGPT_STACK_DEPTH_MAX>), grid_deep, block, 0, c->stream, sc, queue, count_ptr,
+                               count_imm, work_head, ro, rd, hits, occ, c->counters.p);
+    } else if (count)
+        hipLaunchKernelGGL((k_trace<ANY, true, AGPT_STACK_DEPTH>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm,
+                           work_head, ro, rd, hits, occ, c->counters.p);
     else
-        hipLaunchKernelGGL((k_trace<ANY, false>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
-                           hits, occ, c->counters.p);
+        hipLaunchKernelGGL((k_trace<ANY, false, AGPT_STACK_DEPTH>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm,
+                           work_head, ro, rd, hits, occ, c->counters.p);
 }
 
 static hipEvent_t next_event(agpt_ctx* c) {
@@ -374,9 +382,9 @@ int agpt_scene_commit(agpt_scene* s) {
     agpt::FlatScene flat;
     agpt::flatten_scene(s->meshes, s->spheres, s->prims, flat);
     s->max_depth = flat.max_depth;
-    if (flat.max_depth > AGPT_STACK_DEPTH)
+    if (flat.max_depth > AGPT_STACK_DEPTH_MAX)
         return fail(AGPT_ERR_LIMIT, "agpt_scene_commit: BVH depth " + std::to_string(flat.max_depth) +
-                                        " exceeds the traversal stack (" + std::to_string(AGPT_STACK_DEPTH) + ")");
+                                        " exceeds the deepest traversal stack (" + std::to_string(AGPT_STACK_DEPTH_MAX) + ")");
     std::vector<DevLight> lights(s->lights.size());
     int n_inf = 0;
     for (size_t i = 0; i < lights.size(); i++) {
@@ -426,6 +434,7 @@ int agpt_scene_commit(agpt_scene* s) {
     s->dev.n_lights = (int)lights.size();
     s->dev.n_materials = (int)s->materials.size();
     s->dev.n_infinite = n_inf;
+    s->dev.max_depth = flat.max_depth;
     s->dev.n_meshes = 0;
     for (const DevPrim& dp : flat.prims)
         if (dp.type == AGPT_PRIM_MESH && dp.n_tris > 0) s->dev.n_meshes++;

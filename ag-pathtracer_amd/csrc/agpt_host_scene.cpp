@@ -427,8 +427,17 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
                 else
                     w |= AGPT_NODE_BIGLEAF;
             }
-            out.nodes[2 * (nb + i)] = F4(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0]);
-            out.nodes[2 * (nb + i) + 1] = F4(n.bmax[1], n.bmax[2], bits(z), bits(w));
+            // sibling pairs (node indices 2k, 2k+1) share one 64-B record with the two boxes interleaved component by
+            // component, so a lane's four 16-B loads land as (left, right) register pairs for packed-fp32 slab maths:
+            //   [0] lx0 rx0 ly0 ry0   [1] lz0 rz0 lx1 rx1   [2] ly1 ry1 lz1 rz1   [3] zL zR wL wR
+            float* rec = reinterpret_cast<float*>(&out.nodes[4 * ((nb + i) >> 1)]);
+            const size_t side = (nb + i) & 1;
+            for (int a = 0; a < 3; a++) {
+                rec[2 * a + side] = n.bmin[a];
+                rec[6 + 2 * a + side] = n.bmax[a];
+            }
+            rec[12 + side] = bits(z);
+            rec[14 + side] = bits(w);
         }
         {
             const agpt_bvh_node& r = mesh.nodes[0];

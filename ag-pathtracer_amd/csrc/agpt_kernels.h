@@ -94,12 +94,13 @@ __device__ __forceinline__ void queue_push(uint32_t* q, uint32_t* count, bool pr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <bool ANY, bool COUNT>
+// DEPTH: per-lane stack entries (32, or 64 for BVHs deeper than AGPT_STACK_DEPTH: 64 KiB of LDS per block)
+template <bool ANY, bool COUNT, int DEPTH>
 __global__ void __launch_bounds__(AGPT_BLOCK)
 k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
         uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
         DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters) {
-    __shared__ uint32_t s_stack[AGPT_STACK_DEPTH * AGPT_BLOCK];
+    __shared__ uint32_t s_stack[DEPTH * AGPT_BLOCK];
     uint32_t* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
@@ -343,19 +344,15 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             const int nA = __popcll(__ballot(wantA)), nB = __popcll(__ballot(wantB)), nC = __popcll(__ballot(wantC));
             if (nB * vote_b >= nA * vote_a && nB * vote_b >= nC * vote_c) {
                 if (wantB) {
-                    const float4* np = sc.nodes + 2 * (size_t)cur;
-                    float4 a0 = np[0], a1 = np[1], b0 = np[2], b1 = np[3];
+                    const NodePair np = load_pair(sc, cur);
                     float dl, dr;
-                    bool hl = box_test_fast(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
-                    bool hr = box_test_fast(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
+                    bool hl, hr;
+                    pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
                     if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
-                        if (!r.fast) {
-                            hl = box_test_t<false>(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
-                            hr = box_test_t<false>(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
-                        }
+                        if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
                     }
-                    uint32_t encl = encode_child(cur, __float_as_uint(a1.z), __float_as_uint(a1.w));
-                    uint32_t encr = encode_child(cur + 1, __float_as_uint(b1.z), __float_as_uint(b1.w));
+                    uint32_t encl = encode_child(cur, __float_as_uint(np.n3.x), __float_as_uint(np.n3.z));
+                    uint32_t encr = encode_child(cur + 1, __float_as_uint(np.n3.y), __float_as_uint(np.n3.w));
                     if (hl && hr) {
                         bool swap = ANY ? false : (dr < dl);
                         stack[sp * AGPT_BLOCK] = swap ? encl : encr;
@@ -376,9 +373,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                 if (wantC) {
                     uint32_t first, cnt;
                     if ((cur & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
-                        float4 n1 = sc.nodes[2 * (size_t)(cur & 0x0FFFFFFFu) + 1];
-                        first = __float_as_uint(n1.z);
-                        cnt = __float_as_uint(n1.w) & ~AGPT_NODE_BIGLEAF;
+                        node_words(sc, cur & 0x0FFFFFFFu, first, cnt);
+                        cnt &= ~AGPT_NODE_BIGLEAF;
                     } else {
                         first = cur & 0x0FFFFFFFu;
                         cnt = ((cur >> 28) & 7u) + 1u;

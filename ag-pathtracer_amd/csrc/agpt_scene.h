@@ -1,11 +1,13 @@
 // agpt_scene.h -- flat, HBM-resident scene representation shared by the host builder and the kernels.
 //
 // Layout (all arrays 64-B aligned, replicated per GPU):
-//   nodes      float4[2*N]  reference BVHNode layout (bvhtrimesh.h:126-130): {bmin.xyz,bmax.x}{bmax.yz,first,count}, with
-//                           `first` replaced by the node's precomputed traversal encoding (interior: child-pair index,
-//                           leaf: flag|count|first slot);
-//                           sibling pairs share a 64-B line; all meshes concatenated, `first` rebased to global
-//                           node / triangle-slot indices
+//   nodes      float4[2*N]  the reference's 32-B BVHNode content (bvhtrimesh.h:126-130: bounds, first, count), stored per
+//                           SIBLING PAIR: nodes 2k and 2k+1 (always fetched together, bvhtrimesh.h:350-351) share one
+//                           64-B line with their boxes interleaved component-wise --
+//                             [4k+0] lx0 rx0 ly0 ry0  [4k+1] lz0 rz0 lx1 rx1  [4k+2] ly1 ry1 lz1 rz1  [4k+3] zL zR wL wR
+//                           z = the node's precomputed traversal encoding (interior: child-pair index, leaf:
+//                           flag|count-1|first slot), w = count | AGPT_NODE_BIGLEAF; all meshes concatenated,
+//                           indices rebased to global node / triangle-slot indices
 //   tri_verts  float4[3*T]  per REORDERED primitive slot (BVH leaf order): v0,v1,v2; v0.w = global triangle id,
 //                           v1.w = flags (bit0: degenerate-reject, quirk 11), v2.w unused.  Replaces the reference's
 //                           primitives[] -> indices[] -> vertices[] double indirection (88 B/test -> 48 B/test)
@@ -29,7 +31,8 @@
 #define AGPT_HIT_SPHERE 0x80000000u   // analytic primitive (sphere or plane): low bits = primitive index
 
 #define AGPT_TRI_FLAG_REJECT 1u     // degenerate triangle: TriangleIntersect returns false after the t test
-#define AGPT_STACK_DEPTH 32         // per-lane traversal stack entries staged in LDS
+#define AGPT_STACK_DEPTH 32         // per-lane traversal stack entries staged in LDS (production kernel)
+#define AGPT_STACK_DEPTH_MAX 64     // deepest BVH the generic kernel's 64-entry variant can walk
 
 // traversal-stack / node encoding: bit31 = leaf.  leaf with count<=7: bits 28..30 = count-1, bits 0..27 = first slot.
 // leaf with more prims (identical centroids, bvhtrimesh.h:235-238): 0xF0000000 | node index (node is re-fetched).
@@ -96,6 +99,7 @@ struct DevScene {
     int32_t n_prims, n_lights, n_materials;
     int32_t n_infinite;        // number of IsInfinite() lights
     int32_t n_meshes;          // non-empty mesh primitives
+    int32_t max_depth;         // deepest BVH of the scene (selects the traversal-stack size)
     DevCamera cam;
 };
 

@@ -88,6 +88,41 @@ __device__ __forceinline__ bool box_test_fast(float bx0, float by0, float bz0, f
     dist = tmin;
     return !((tmax * 1.00000024f) < tmin);
 }
+// The two children of an interior node come from one interleaved 64-B pair record (agpt_host_scene.cpp:
+// flatten_scene): the four 16-B loads land so that no register shuffling is needed before the slab arithmetic.
+// (Issuing the two boxes as packed fp32 -- v_pk_add/mul/fma_f32 on (left, right) pairs -- was measured 5 % SLOWER on
+// gfx950 than the scalar form below: a packed op costs more than two scalar ones here.  For the same reason the
+// library is built with -fno-slp-vectorize, see build.py.)
+struct NodePair {
+    float4 n0, n1, n2, n3;
+};
+__device__ __forceinline__ NodePair load_pair(const DevScene& sc, uint32_t left) {
+    const float4* np = sc.nodes + 2 * (size_t)left;
+    NodePair p;
+    p.n0 = np[0];
+    p.n1 = np[1];
+    p.n2 = np[2];
+    p.n3 = np[3];
+    return p;
+}
+__device__ __forceinline__ void pair_boxes_fast(const NodePair& p, const TraceRay& r, float rayt, bool& hl, bool& hr,
+                                                float& dl, float& dr) {
+    hl = box_test_fast(p.n0.x, p.n0.z, p.n1.x, p.n1.z, p.n2.x, p.n2.z, r, rayt, dl);
+    hr = box_test_fast(p.n0.y, p.n0.w, p.n1.y, p.n1.w, p.n2.y, p.n2.w, r, rayt, dr);
+}
+// reference-order (true division) tests of the same record
+__device__ __forceinline__ void pair_boxes_exact(const NodePair& p, const TraceRay& r, float rayt, bool& hl, bool& hr,
+                                                 float& dl, float& dr) {
+    hl = box_test_t<false>(p.n0.x, p.n0.z, p.n1.x, p.n1.z, p.n2.x, p.n2.z, r, rayt, dl);
+    hr = box_test_t<false>(p.n0.y, p.n0.w, p.n1.y, p.n1.w, p.n2.y, p.n2.w, r, rayt, dr);
+}
+// z / w words (traversal encoding, count | flags) of ONE node of the interleaved array
+__device__ __forceinline__ void node_words(const DevScene& sc, uint32_t node, uint32_t& z, uint32_t& w) {
+    const uint32_t* rec = reinterpret_cast<const uint32_t*>(sc.nodes + 4 * (size_t)(node >> 1));
+    z = rec[12 + (node & 1)];
+    w = rec[14 + (node & 1)];
+}
+
 __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
                                          const TraceRay& r, float rayt, float& dist) {
     if (__builtin_expect(r.fast, 1)) return box_test_fast(bx0, by0, bz0, bx1, by1, bz1, r, rayt, dist);
@@ -244,14 +279,16 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
             }
             if (!(cur & AGPT_ENC_LEAF)) {
                 // interior: fetch the child pair (one 64-B line)
-                const float4* np = sc.nodes + 2 * (size_t)cur;
-                float4 a0 = np[0], a1 = np[1], b0 = np[2], b1 = np[3];
+                const NodePair np = load_pair(sc, cur);
                 if (COUNT) cnt.interior++;
                 float dl, dr;
-                bool hl = box_test(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, r, rayt, dl);
-                bool hr = box_test(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r, rayt, dr);
-                uint32_t encl = encode_child(cur, __float_as_uint(a1.z), __float_as_uint(a1.w));
-                uint32_t encr = encode_child(cur + 1, __float_as_uint(b1.z), __float_as_uint(b1.w));
+                bool hl, hr;
+                if (__builtin_expect(r.fast, 1))
+                    pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
+                else
+                    pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
+                uint32_t encl = encode_child(cur, __float_as_uint(np.n3.x), __float_as_uint(np.n3.z));
+                uint32_t encr = encode_child(cur + 1, __float_as_uint(np.n3.y), __float_as_uint(np.n3.w));
                 if (hl && hr) {
                     bool swap = ANY ? false : (dr < dl);
                     uint32_t nearn = swap ? encr : encl;
@@ -270,10 +307,8 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
             } else {
                 uint32_t first, count;
                 if ((cur & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
-                    const float4* np = sc.nodes + 2 * (size_t)(cur & 0x0FFFFFFFu);
-                    float4 n1 = np[1];
-                    first = __float_as_uint(n1.z);
-                    count = __float_as_uint(n1.w) & ~AGPT_NODE_BIGLEAF;
+                    node_words(sc, cur & 0x0FFFFFFFu, first, count);
+                    count &= ~AGPT_NODE_BIGLEAF;
                 } else {
                     first = cur & 0x0FFFFFFFu;
                     count = ((cur >> 28) & 7u) + 1u;

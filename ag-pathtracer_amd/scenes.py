@@ -243,6 +243,68 @@ def scene_c2(n_seg=187, backdrop=None, aspect=16.0 / 9.0):
     return d
 
 
+def _merge(parts):
+    vs, ns, ts, ixs, base = [], [], [], [], 0
+    for (v, n, t, ix) in parts:
+        vs.append(v); ns.append(n); ts.append(t); ixs.append(ix + base); base += v.shape[0]
+    return np.concatenate(vs), np.concatenate(ns), np.concatenate(ts), np.concatenate(ixs)
+
+
+def _atrium_furniture(rng, q, emit):
+    """Columns, arches, drapes and urns of the C3 atrium; every finished mesh goes to emit((v, n, t, idx))."""
+    # two rows of displaced columns
+    col_x = np.linspace(-11.0, 11.0, 6)
+    for zc in (-3.6, 3.6):
+        for xc in col_x:
+            ph = rng.uniform(0, 2 * np.pi, 3)
+            flutes = int(rng.choice([8, 12, 16]))
+
+            def col(U, V, xc=xc, zc=zc, ph=ph, flutes=flutes):
+                a = 2 * np.pi * U
+                y = 9.0 * V
+                r = 0.55 + 0.04 * np.cos(flutes * a + ph[0]) + 0.10 * np.exp(-((V - 0.02) / 0.05) ** 2) \
+                    + 0.12 * np.exp(-((V - 0.98) / 0.04) ** 2) + 0.02 * np.sin(6 * np.pi * V + ph[1])
+                return np.stack([xc + r * np.cos(a), y, zc + r * np.sin(a)], -1)
+            emit(grid_mesh(col, q(62), q(80), flip=True))
+
+    # arches spanning neighbouring columns (half tori), grouped per row pair
+    for i in range(5):
+        parts = []
+        for zc in (-3.6, 3.6):
+            x0, x1 = col_x[i], col_x[i + 1]
+            cx, R = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
+
+            def arch(U, V, cx=cx, R=R, zc=zc):
+                a = np.pi * U
+                b = 2 * np.pi * V
+                rr = 0.32 + 0.03 * np.cos(8 * b)
+                return np.stack([cx - (R + rr * np.cos(b)) * np.cos(a), 9.0 + (R + rr * np.cos(b)) * np.sin(a) * 0.6,
+                                 zc + rr * np.sin(b)], -1)
+            parts.append(grid_mesh(arch, q(44), q(30)))
+        emit(_merge(parts))
+
+    # drapes: wavy hanging sheets along the side aisles
+    for i in range(6):
+        xc = -10.0 + 4.0 * i
+        zc = -5.6 if i % 2 == 0 else 5.6
+        ph = rng.uniform(0, 2 * np.pi, 2)
+
+        def drape(U, V, xc=xc, zc=zc, ph=ph):
+            x = xc + 3.0 * (U - 0.5)
+            y = 9.5 - 6.5 * V
+            z = zc + 0.35 * np.sin(9 * U * np.pi + ph[0]) * (0.3 + V) + 0.1 * np.sin(5 * V * np.pi + ph[1])
+            return np.stack([x, y, z], -1)
+        emit(grid_mesh(drape, q(60), q(60)))
+
+    # urns on the floor between the columns
+    for i in range(8):
+        xc = -9.9 + 2.83 * i
+        zc = 0.0 if i % 2 == 0 else (-1.2 if i % 4 == 1 else 1.2)
+        v, n, t, ix = blob_mesh(q(40), q(40), center=(xc, 0.78, zc), radius=0.7, seed=int(rng.randint(1 << 30)))
+        emit((v, n, t, ix))
+
+
+
 def scene_c3(scale=1.0, aspect=16.0 / 9.0, seed=0xA6A70003 & 0x7FFFFFFF, all_metal=False):
     """C3 "Sponza-class": a closed atrium (room 30 x 12 x 14) with two rows of displaced columns, arches, drapes and
     urns from tessellated grids, ~260k triangles at scale=1, ~30 Disney materials (roughness U[.2,1], 15 % metals,
@@ -267,11 +329,7 @@ def scene_c3(scale=1.0, aspect=16.0 / 9.0, seed=0xA6A70003 & 0x7FFFFFFF, all_met
         o, eu, ev = map(np.asarray, (o, eu, ev))
         return grid_mesh(lambda U, V: o + U[..., None] * eu + V[..., None] * ev, nu, nv, flip)
 
-    def merge(parts):
-        vs, ns, ts, ixs, base = [], [], [], [], 0
-        for (v, n, t, ix) in parts:
-            vs.append(v); ns.append(n); ts.append(t); ixs.append(ix + base); base += v.shape[0]
-        return np.concatenate(vs), np.concatenate(ns), np.concatenate(ts), np.concatenate(ixs)
+    merge = _merge
 
     # floor, ceiling with an open strip (|z| < 1.5 for |x| < 11), walls
     d.add_mesh(*plane([-X, 0, -Z], [2 * X, 0, 0], [0, 0, 2 * Z], q(110), q(52), flip=True), material())
@@ -285,61 +343,53 @@ def scene_c3(scale=1.0, aspect=16.0 / 9.0, seed=0xA6A70003 & 0x7FFFFFFF, all_met
     d.add_mesh(*merge([plane([-X, 0, -Z], [0, 0, 2 * Z], [0, Y, 0], q(50), q(42)),
                        plane([X, 0, -Z], [0, 0, 2 * Z], [0, Y, 0], q(50), q(42), flip=True)]), material())
 
-    # two rows of displaced columns
-    col_x = np.linspace(-11.0, 11.0, 6)
-    for zc in (-3.6, 3.6):
-        for xc in col_x:
-            ph = rng.uniform(0, 2 * np.pi, 3)
-            flutes = int(rng.choice([8, 12, 16]))
-
-            def col(U, V, xc=xc, zc=zc, ph=ph, flutes=flutes):
-                a = 2 * np.pi * U
-                y = 9.0 * V
-                r = 0.55 + 0.04 * np.cos(flutes * a + ph[0]) + 0.10 * np.exp(-((V - 0.02) / 0.05) ** 2) \
-                    + 0.12 * np.exp(-((V - 0.98) / 0.04) ** 2) + 0.02 * np.sin(6 * np.pi * V + ph[1])
-                return np.stack([xc + r * np.cos(a), y, zc + r * np.sin(a)], -1)
-            d.add_mesh(*grid_mesh(col, q(62), q(80), flip=True), material())
-
-    # arches spanning neighbouring columns (half tori), grouped per row pair
-    for i in range(5):
-        parts = []
-        for zc in (-3.6, 3.6):
-            x0, x1 = col_x[i], col_x[i + 1]
-            cx, R = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
-
-            def arch(U, V, cx=cx, R=R, zc=zc):
-                a = np.pi * U
-                b = 2 * np.pi * V
-                rr = 0.32 + 0.03 * np.cos(8 * b)
-                return np.stack([cx - (R + rr * np.cos(b)) * np.cos(a), 9.0 + (R + rr * np.cos(b)) * np.sin(a) * 0.6,
-                                 zc + rr * np.sin(b)], -1)
-            parts.append(grid_mesh(arch, q(44), q(30)))
-        d.add_mesh(*merge(parts), material())
-
-    # drapes: wavy hanging sheets along the side aisles
-    for i in range(6):
-        xc = -10.0 + 4.0 * i
-        zc = -5.6 if i % 2 == 0 else 5.6
-        ph = rng.uniform(0, 2 * np.pi, 2)
-
-        def drape(U, V, xc=xc, zc=zc, ph=ph):
-            x = xc + 3.0 * (U - 0.5)
-            y = 9.5 - 6.5 * V
-            z = zc + 0.35 * np.sin(9 * U * np.pi + ph[0]) * (0.3 + V) + 0.1 * np.sin(5 * V * np.pi + ph[1])
-            return np.stack([x, y, z], -1)
-        d.add_mesh(*grid_mesh(drape, q(60), q(60)), material())
-
-    # urns on the floor between the columns
-    for i in range(8):
-        xc = -9.9 + 2.83 * i
-        zc = 0.0 if i % 2 == 0 else (-1.2 if i % 4 == 1 else 1.2)
-        v, n, t, ix = blob_mesh(q(40), q(40), center=(xc, 0.78, zc), radius=0.7, seed=int(rng.randint(1 << 30)))
-        d.add_mesh(v, n, t, ix, material())
+    _atrium_furniture(rng, q, lambda m: d.add_mesh(*m, material()))
 
     d.add_area_light([-6.0, 10.2, 0.0], 0.6, KEY_LIGHT * F(90))
     d.add_area_light([7.0, 9.8, 0.8], 0.5, KEY_LIGHT * F(70))
     d.add_uniform_infinite_light([.4, .45, .5])
     d.set_camera([-13.2, 4.2, 5.4], [6.0, 4.0, -1.5], [0, 1, 0], aspect, 58.0, 0.0)
+    return d
+
+
+def scene_c5(scale=1.0, aspect=16.0 / 9.0, seed=0xA6A70005 & 0x7FFFFFFF):
+    """C5 "5M-triangle multi-mesh": a 4 x 4 field of open colonnades -- 16 instances-by-copy of the C3 furniture
+    (columns, arches, drapes, urns; every copy re-generated from its own seed, so the geometry is perturbed, and merged
+    into ONE mesh) -- standing on an 887 x 887 heightfield terrain; ~5.0 M triangles at scale=1 in 17 meshes, so
+    Scene's linear primitive loop (scene.h:5-19) and BVHs far larger than the L2 are exercised.  All-metal GGX
+    (metallic 1, roughness U[.1,.6]) + MIS, four sphere lights + uniform sky.  3840x2160, 1024 spp on 8 GPUs."""
+    rng = np.random.RandomState(seed)
+    d = SceneDesc("C5-5M-multi-mesh")
+    k = float(np.sqrt(scale))
+
+    def q(n):
+        return max(2, int(round(n * k)))
+
+    def metal():
+        color = hex2lin(CUTE_PALETTE[rng.randint(len(CUTE_PALETTE))])
+        return d.add_material(MAT_DISNEY, color, float(rng.uniform(.1, .6)), 1.0)
+
+    n_t = q(887)
+    ext = 88.0
+
+    def terrain(U, V):
+        x = ext * (2 * U - 1)
+        z = ext * (2 * V - 1)
+        y = -0.35 + 0.30 * np.sin(0.31 * x) * np.cos(0.27 * z) + 0.12 * np.sin(0.93 * x + 1.0) * np.sin(0.79 * z) \
+            + 0.02 * np.sin(4.1 * x) * np.sin(3.7 * z)
+        return np.stack([x, y, z], -1)
+    d.add_mesh(*grid_mesh(terrain, n_t, n_t, flip=True), metal())
+    for i in range(16):
+        parts = []
+        _atrium_furniture(np.random.RandomState((seed + 7919 * (i + 1)) & 0x7FFFFFFF), q, parts.append)
+        v, n, t, ix = _merge(parts)
+        off = np.array([-51.0 + 34.0 * (i % 4), 0.0, -33.0 + 22.0 * (i // 4)], F)
+        v = (v * F(rng.uniform(0.94, 1.06)) + off).astype(F)
+        d.add_mesh(v, n, t, ix, metal())
+    for (x, z, r, pw) in ((-40.0, -20.0, 3.0, 260), (38.0, 24.0, 2.5, 300), (-10.0, 40.0, 2.0, 340), (20.0, -44.0, 2.0, 340)):
+        d.add_area_light([x, 34.0, z], r, KEY_LIGHT * F(pw))
+    d.add_uniform_infinite_light([.4, .45, .5])
+    d.set_camera([-84.0, 44.0, 62.0], [-4.0, -8.0, -2.0], [0, 1, 0], aspect, 40.0, 0.0)
     return d
 
 

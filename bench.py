@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU-share (total = spp * gpus)")
     ap.add_argument("--scene-scale", type=float, default=1.0)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+                    help="c3 = the BASELINE metric's configuration (default); c5 = the 5M-triangle multi-mesh scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--samples-per-batch", type=int, default=0)
     args = ap.parse_args()
@@ -134,7 +136,12 @@ def main():
 
     W, H, MAXD = args.width, args.height, 5
     spp = args.spp * world
-    desc = ag.scenes.scene_c3(scale=args.scene_scale, aspect=W / float(H))
+    if args.workload == "c5":
+        desc = ag.scenes.scene_c5(scale=args.scene_scale, aspect=W / float(H))
+        wl_name = "BASELINE configs[4] geometry: 5M-triangle multi-mesh colonnade field, all-metal GGX"
+    else:
+        desc = ag.scenes.scene_c3(scale=args.scene_scale, aspect=W / float(H))
+        wl_name = "BASELINE configs[2]: Sponza-class closed atrium"
     ctx = ag.Context(dev_index, stream=torch.cuda.current_stream().cuda_stream)
     scene = desc.instantiate(ag.Scene(ctx))
     pt = ag.PathTracer(MAXD)
@@ -209,7 +216,7 @@ def main():
         achieved = bytes_per_ray * rays_rank0 / trace_s / 1e9 if trace_s > 0 else 0.0
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and args.workload == "c3":
             try:
                 traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001
@@ -221,9 +228,9 @@ def main():
             "ms_per_step": round(dt_max / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: Sponza-class closed atrium, %d tris / %d primitives / %d Disney materials, "
+                "workload": "%s, %d tris / %d primitives / %d Disney materials, "
                             "%dx%d, %d spp (%d spp x %d GPU shares), PathTracer MaxDepth=5, NEE+MIS"
-                            % (desc.n_tris, desc.n_prims, desc.n_materials, W, H, spp, args.spp, world),
+                            % (wl_name, desc.n_tris, desc.n_prims, desc.n_materials, W, H, spp, args.spp, world),
                 "triangles": desc.n_tris, "resolution": [W, H], "spp": spp, "sharding": "8-row blocks round-robin, gather to rank 0",
                 "rays_per_step": int(rays_total / args.steps), "rays_per_sample": round(rays_total / args.steps / (W * H * spp), 2),
                 "msamples_per_s": round(W * H * spp * args.steps / dt_max / 1e6, 2),

@@ -39,7 +39,7 @@ def test_c3_full_scene_1080p_tile_vs_oracle_and_invariances():
     tile = (912, 500, 96, 54)
     oacc, ost = oracle_tile(desc, W, H, spp, tile)
     a, b = tile_rows(full, H, tile), tile_rows(oacc, H, tile)
-    assert np.mean(np.all(a.view(np.uint32) == b.view(np.uint32), axis=-1)) >= 0.999
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     # (b1) determinism
     again, st2 = pt.render_to_host(g, W, H, spp)
     assert again.tobytes() == full.tobytes() and st2.rays == st.rays
@@ -87,7 +87,7 @@ def test_c2_full_size_tile_vs_oracle():
     tile = (600, 330, 96, 54)
     oacc, ost = oracle_tile(desc, W, H, spp, tile)
     a, b = tile_rows(full, H, tile), tile_rows(oacc, H, tile)
-    assert np.mean(np.all(a.view(np.uint32) == b.view(np.uint32), axis=-1)) >= 0.999
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert st.outliers == 0
 
 
@@ -100,5 +100,77 @@ def test_c5_class_all_metal_multi_mesh():
     g.close()
     oacc, ost = oracle_tile(desc, W, H, spp, (0, 0, W, H))
     same = np.all(acc[..., :3].view(np.uint32) == oacc[..., :3].view(np.uint32), axis=-1)
-    assert same.mean() >= 0.999
+    assert same.all()
     assert st.rays == ost.rays
+
+
+def gather_ranks(pt, g, W, H, spp, world):
+    ctx = g.ctx
+    ptr = ctx.alloc(W * H * 16)
+    bufs = []
+    for r in range(world):
+        rows = tiles.max_local_rows(H, world)
+        ctx.memset(ptr, 0, W * H * 16)
+        pt.render(g, W, H, spp, ptr, interleave=(tiles.BLOCK_ROWS, world, r))
+        bufs.append(ctx.download(ptr, (H, W, 4))[:rows].copy())
+    ctx.free(ptr)
+    return tiles.deinterleave(bufs, W, H, world)
+
+
+def test_c4_same_scene_4k_split_over_8_ranks():
+    """BASELINE config 4: the C3 scene at 3840x2160 (256 spp in the config; 1 spp here), framebuffer split over 8 ranks.
+    The 8 rank shares, gathered, are the single-GPU film bit for bit; two oracle tiles pin the film itself."""
+    W, H, spp = 3840, 2160, 1
+    desc = ag.scenes.scene_c3()
+    g = gpu_scene(desc)
+    pt = ag.PathTracer(5)
+    full, st = pt.render_to_host(g, W, H, spp)
+    assert st.samples == W * H * spp and st.outliers == 0
+    assert gather_ranks(pt, g, W, H, spp, 8).tobytes() == full.tobytes()
+    g.close()
+    for tile in ((1800, 1000, 96, 54), (300, 1700, 64, 64)):
+        oacc, _ = oracle_tile(desc, W, H, spp, tile)
+        a, b = tile_rows(full, H, tile), tile_rows(oacc, H, tile)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_c5_five_million_triangles_17_meshes():
+    """BASELINE config 5: ~5 M triangles in 17 meshes (16 perturbed colonnade copies + a terrain), all-metal GGX + MIS,
+    3840x2160 (1024 spp on 8 GPUs in the config; 1 spp here).  Same BVHs as the oracle's builder, same hits and
+    node / triangle visit counts on random rays, oracle tiles of the 4K film bit-exact, 8-rank split == full film."""
+    W, H, spp = 3840, 2160, 1
+    desc = ag.scenes.scene_c5()
+    assert 4.9e6 <= desc.n_tris <= 5.1e6 and desc.n_prims == 21
+    g = gpu_scene(desc)
+    o = oracle_scene(desc)
+    for prim in (0, 1, 16):
+        gn, go = g.bvh(prim)
+        on, oo = o.bvh(prim)
+        assert gn.tobytes() == on.tobytes() and np.array_equal(go, oo)
+    from helpers import random_rays, bits
+    rays = random_rays(desc, 200000, seed=5)
+    gh, gst = g.Intersect(rays, counters=True)
+    gf, _ = g.Intersect(rays)
+    oh, ost = o.intersect(rays, any_hit=False)
+    assert gh.tobytes() == gf.tobytes()
+    m = oh["hit"] == 1
+    assert m.sum() > 20000
+    assert np.array_equal(gh["hit"], oh["hit"]) and np.array_equal(gh["prim"], oh["prim"]) and np.array_equal(gh["tri"], oh["tri"])
+    assert np.array_equal(bits(gh["t"][m]), bits(oh["t"][m]))
+    assert gst.interior_visits == ost.interior_visits and gst.tri_tests == ost.tri_tests
+    gp, _ = g.IntersectP(rays)
+    op_, _ = o.intersect(rays, any_hit=True)
+    assert np.array_equal(gp["hit"], op_["hit"])
+    pt = ag.PathTracer(5)
+    full, st = pt.render_to_host(g, W, H, spp)
+    assert st.samples == W * H * spp and st.outliers == 0
+    assert gather_ranks(pt, g, W, H, spp, 8).tobytes() == full.tobytes()
+    g.close()
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        for tile in ((1900, 900, 96, 54), (700, 400, 64, 64), (3000, 1500, 64, 48)):
+            oacc, _ = o.render(W, H, spp, tile=tile, threads=8)
+            a, b = tile_rows(full, H, tile), tile_rows(oacc, H, tile)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)

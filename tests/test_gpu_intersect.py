@@ -141,3 +141,62 @@ def test_plane_primitive():
     extra["tmax"] = 3.402823466e+38
     check_closest(d, np.concatenate([rays, extra]))
     compare(d, 96, 96, 2)
+
+
+def test_deep_bvh_uses_the_64_entry_stack():
+    """A pathological mesh whose binned-SAH tree (depth 39) is deeper than the production kernel's 32-entry stack:
+    triangle sizes in geometric progression (x8) along one axis make every split peel off one triangle."""
+    n = 40
+    v, tris, scale = [], [], []
+    x = 0.0
+    for i in range(n):
+        w = 8.0 ** (i - n // 2)
+        v += [[x, 0, 0], [x + w, 0, 0], [x, w, 0]]
+        tris.append([3 * i, 3 * i + 1, 3 * i + 2])
+        scale.append(w)
+        x += w * 1.5
+    v = np.array(v, np.float32)
+    idx = np.stack([np.array(tris, np.int32).reshape(-1)] * 3, 1)
+    nodes, order, depth = ag.bvh_build(v, idx, 1)
+    assert depth > 32
+    d = ag.SceneDesc("deep")
+    m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
+    d.add_mesh(v, None, None, idx, m, 1)
+    rng = np.random.RandomState(3)
+    rays = np.zeros(20000, ag.RAY_DTYPE)
+    t = rng.randint(n, size=len(rays))
+    w = np.float32(scale)[t][:, None]
+    bary = rng.dirichlet([1, 1, 1], len(rays)).astype(np.float32) * np.float32(1.2) - np.float32(0.05)
+    tgt = (v[3 * t] * bary[:, :1] + v[3 * t + 1] * bary[:, 1:2] + v[3 * t + 2] * bary[:, 2:]).astype(np.float32)
+    rays["o"] = tgt + w * (np.float32([0, 0, 1.0]) + rng.normal(0, 0.3, (len(rays), 3)).astype(np.float32))
+    rays["d"] = tgt - rays["o"]
+    rays["tmax"] = 3.402823466e+38
+    hit = check_closest(d, rays)
+
+
+def test_degenerate_scenes_and_calls():
+    """Only analytic primitives (no mesh), no lights at all, zero samples, a one-triangle mesh (the BVH root is a leaf)."""
+    from test_gpu_render import compare
+    d = ag.SceneDesc("spheres-only")
+    a = d.add_material(ag.MAT_DISNEY, [.8, .6, .2], .3, 1.)
+    b = d.add_material(ag.MAT_DISNEY, [.2, .6, .8], .8, 0.)
+    d.add_sphere([0, 0, 0], 1.0, a)
+    d.add_sphere([0, -101, 0], 100.0, b)
+    d.add_uniform_infinite_light([.7, .7, .7])
+    d.set_camera([0, 1, -5], [0, 0, 0], [0, 1, 0], 1.0, 40.0, 0.0)
+    compare(d, 64, 64, 2)
+    nol = ag.SceneDesc("no-lights")
+    m = nol.add_material(ag.MAT_DISNEY, [.8, .6, .2], .3, 0.)
+    nol.add_mesh(np.float32([[-1, 0, 2], [1, 0, 2], [0, 1, 2]]), None, None, np.stack([np.arange(3, dtype=np.int32)] * 3, 1), m, 1)
+    nol.set_camera([0, .3, -3], [0, .3, 0], [0, 1, 0], 1.0, 40.0, 0.0)
+    compare(nol, 48, 48, 1)
+    g = gpu_scene(nol)
+    ctx = g.ctx
+    ptr = ctx.alloc(48 * 48 * 16)
+    ctx.memset(ptr, 0, 48 * 48 * 16)
+    st = ag.PathTracer(5).render(g, 48, 48, 0, ptr)
+    assert st.rays == 0 and not ctx.download(ptr, (48, 48, 4)).any()
+    with pytest.raises(ag.AgptError):
+        ag.PathTracer(5).render(g, 48, 48, 1, ptr, tile=(40, 40, 16, 16))   # tile outside the film
+    ctx.free(ptr)
+    g.close()

@@ -45,10 +45,10 @@ def compare(desc, W, H, spp, max_depth=5, tile=None, seed_base=0, spb=0):
                 anyhit=(gst.anyhit_rays, ost.anyhit_rays), outliers=(gst.outliers, ost.outliers),
                 interior=(gst.interior_visits, ost.interior_visits), tris=(gst.tri_tests, ost.tri_tests))
     print(desc.name, info)
-    assert info["bit_exact"] >= 0.999, info
+    assert info["bit_exact"] == 1.0, info
     assert info["close"] >= 1 - 1e-4, info
     assert info["mean_rel"] <= 1e-4, info
-    assert abs(gst.rays - ost.rays) <= max(2, 1e-4 * ost.rays), info
+    assert gst.rays == ost.rays, info
     assert gst.outliers == ost.outliers
     return info
 

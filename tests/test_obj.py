@@ -194,5 +194,5 @@ def test_loaded_obj_renders_like_the_oracle(tmp_path):
         oacc, ost = o.render(96, 96, 2, threads=8)
     finally:
         ob.set_trig_mode(ob.TRIG_LIBM)
-    assert np.mean(np.all(acc[..., :3].view(np.uint32) == oacc[..., :3].view(np.uint32), axis=-1)) >= 0.999
+    assert np.mean(np.all(acc[..., :3].view(np.uint32) == oacc[..., :3].view(np.uint32), axis=-1)) == 1.0
     assert st.rays == ost.rays

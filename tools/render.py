@@ -29,7 +29,7 @@ def write_png(path, rgb):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scene", default="c3", choices=["c1", "c2", "c3", "simple", "heightfield"])
+    ap.add_argument("--scene", default="c3", choices=["c1", "c2", "c3", "c5", "simple", "heightfield"])
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--height", type=int, default=540)
     ap.add_argument("--spp", type=int, default=64)
@@ -38,10 +38,13 @@ def main():
     W, H = a.width, a.height
     aspect = W / float(H)
     desc = {"c1": lambda: ag.scenes.scene_c1(), "c2": lambda: ag.scenes.scene_c2(aspect=aspect),
-            "c3": lambda: ag.scenes.scene_c3(aspect=aspect), "simple": lambda: ag.scenes.scene_simple_test(),
+            "c3": lambda: ag.scenes.scene_c3(aspect=aspect), "c5": lambda: ag.scenes.scene_c5(aspect=aspect),
+            "simple": lambda: ag.scenes.scene_simple_test(),
             "heightfield": lambda: ag.scenes.scene_heightfield(361, True, W, H)}[a.scene]()
     ctx = ag.Context(0)
+    t0 = time.time()
     scene = desc.instantiate(ag.Scene(ctx))
+    print("scene build + BVH + upload: %.2f s" % (time.time() - t0))
     ptr = ctx.alloc(W * H * 16)
     ctx.memset(ptr, 0, W * H * 16)
     t0 = time.time()
