@@ -30,7 +30,7 @@ EXPORTS = [
     "agpt_intersect_batch", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
     "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
-    "agpt_obj_free", "agpt_obj_last_error",
+    "agpt_obj_free", "agpt_obj_last_error", "agpt_write_png", "agpt_write_pfm",
 ]
 
 
@@ -267,6 +267,20 @@ class Context:
         _check(self.L.agpt_resolve(self.h, C.c_void_p(accum_ptr), n_pixels, samples,
                                    out.ctypes.data_as(C.POINTER(C.c_uint32))), "agpt_resolve")
         return out
+
+
+def write_png(path, rgb_words, width, height):
+    """agpt_write_png: 0x00RRGGBB words (Context.resolve output), top row first."""
+    a = np.ascontiguousarray(rgb_words, dtype=np.uint32)
+    assert a.size == width * height
+    _check(lib().agpt_write_png(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_uint32)), width, height), "agpt_write_png")
+
+
+def write_pfm(path, accum_host, samples):
+    """agpt_write_pfm: linear float image sum/samples from a host copy of the float4 accumulator [H, W, 4]."""
+    a = np.ascontiguousarray(accum_host, dtype=np.float32)
+    h, w, _ = a.shape
+    _check(lib().agpt_write_pfm(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_float)), w, h, samples), "agpt_write_pfm")
 
 
 class Scene:

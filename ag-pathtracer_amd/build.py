@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagpt_hip.so")
-SOURCES = ["agpt_api.hip", "agpt_host_scene.cpp", "agpt_obj.cpp"]
+SOURCES = ["agpt_api.hip", "agpt_host_scene.cpp", "agpt_obj.cpp", "agpt_image.cpp"]
 HEADERS = ["agpt_math.h", "agpt_scene.h", "agpt_trace.h", "agpt_shade.h", "agpt_kernels.h", "agpt_host_scene.hpp",
            os.path.join("..", "..", "include", "agpt.h")]
 # -ffp-contract=off + no fast-math: every fp32 op rounds on its own, exactly as written (parity with the oracle);

@@ -22,6 +22,13 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+}  // namespace
+namespace agpt {
+// error reporting for the library's other translation units (agpt_image.cpp)
+int report_error(int code, const std::string& msg) { return fail(code, msg); }
+}  // namespace agpt
+namespace {
+
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \

@@ -28,7 +28,8 @@ typedef enum {
     AGPT_ERR_INVALID = -1,   /* bad argument / call order */
     AGPT_ERR_DEVICE = -2,    /* HIP runtime error, no device */
     AGPT_ERR_NOMEM = -3,
-    AGPT_ERR_LIMIT = -4      /* scene exceeds a kernel limit (e.g. BVH deeper than the traversal stack) */
+    AGPT_ERR_LIMIT = -4,     /* scene exceeds a kernel limit (e.g. BVH deeper than the traversal stack) */
+    AGPT_ERR_IO = -5         /* file could not be opened / written (image writers) */
 } agpt_status;
 
 typedef struct agpt_ctx agpt_ctx;
@@ -186,6 +187,13 @@ int agpt_render(agpt_scene*, const agpt_render_params*, float* accum_dev, agpt_s
 /* Accumulator::CopyToSurface (myapp.h:34-41): lin2rgb(sum/samples) -> 0x00RRGGBB.  accum_dev DEVICE float4,
  * out_rgb HOST uint32[w*h] */
 int agpt_resolve(agpt_ctx*, const float* accum_dev, int n_pixels, int samples, uint32_t* out_rgb);
+
+/* Host-only image writers (no GPU work) for headless use; the reference only blits to an OpenGL window
+ * (myapp.cpp:177).  agpt_write_png: rgb = width*height 0x00RRGGBB words as agpt_resolve returns them, top row first
+ * (Accumulator::CopyToSurface order).  agpt_write_pfm: accum_host = a HOST copy of the float4 accumulator (row 0 =
+ * top image row, myapp.h:24); writes sum/samples as little-endian RGB float32, bottom row first. */
+int agpt_write_png(const char* path, const uint32_t* rgb, int width, int height);
+int agpt_write_pfm(const char* path, const float* accum_host, int width, int height, int samples);
 
 /* device memory helpers for hosts that do not bring their own allocator (tests, the C++ adapter) */
 int agpt_device_alloc(agpt_ctx*, size_t bytes, void** out_dev);

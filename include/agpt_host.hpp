@@ -19,11 +19,13 @@
 //   Scene::Intersect / IntersectP                  scene.h:5-19      scene.Intersect(rays, n, hits) / IntersectP
 //   PathTracer(maxDepth).Li per pixel + Accumulator::AddSample       agpt::PathTracer(maxDepth).Render(scene, accum, spp)
 //   Accumulator (sum buffer, y flip, sample count) myapp.h:8-68      agpt::Accumulator
+//   RotatingCamera(desc).update(angle)             camera.h:109-162  agpt::RotatingCamera(desc).update(dx, dy) -> CameraDesc
 //
 // Errors: the reference has no error returns (bool hit/miss, exit() on load failure); here every failing C call
 // throws agpt::Error carrying agpt_last_error().
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -165,6 +167,8 @@ public:
         check(agpt_scene_set_camera(h_, &camera), "agpt_scene_set_camera");
         check(agpt_scene_commit(h_), "agpt_scene_commit");
     }
+    // camera moved (RotatingCamera::update): re-derive the camera only, geometry stays in HBM
+    void set_camera() { check(agpt_scene_set_camera(h_, &camera), "agpt_scene_set_camera"); }
     void Intersect(const agpt_ray* rays, int n, agpt_hit* hits) const {
         check(agpt_intersect_batch(h_, rays, n, hits, 0, nullptr), "agpt_intersect_batch");
     }
@@ -184,6 +188,43 @@ public:
 private:
     Context& ctx_;
     agpt_scene* h_ = nullptr;
+};
+
+// RotatingCamera (camera.h:109-162): orbit around lookat at a fixed distance.  The elevation angle is clamped to
+// [-(pi/2 - 1e-4), 0] and lookfrom = RotateY(yAngle) * RotateX(xAngle) * (0,0,1) * dist + lookat.  The host applies the
+// result with `scene.camera = cam.update(dx, dy); scene.set_camera(); accumulator.Clear();` (myapp.cpp:143-149).
+class RotatingCamera {
+public:
+    explicit RotatingCamera(const CameraDesc& d) : desc_(d) {
+        const float fx = d.lookfrom[0] - d.lookat[0], fy = d.lookfrom[1] - d.lookat[1], fz = d.lookfrom[2] - d.lookat[2];
+        dist_ = std::sqrt(fx * fx + fy * fy + fz * fz);
+        const float inv = 1.0f / dist_;
+        const float nx = fx * inv, ny = fy * inv, nz = fz * inv;
+        const float horiz = std::sqrt(nx * nx + nz * nz);
+        xAngle_ = std::acos(horiz);
+        if (ny > 0) xAngle_ = -xAngle_;
+        yAngle_ = std::acos(nz / horiz);
+        if (nx < 0) yAngle_ = -yAngle_;
+    }
+    const CameraDesc& update(float dxAngle, float dyAngle) {
+        const float lim = 3.14159265358979323846f / 2 - 0.0001f;
+        xAngle_ += dxAngle;
+        xAngle_ = xAngle_ < -lim ? -lim : (xAngle_ > 0.f ? 0.f : xAngle_);
+        yAngle_ += dyAngle;
+        const float cx = std::cos(xAngle_), sx = std::sin(xAngle_), cy = std::cos(yAngle_), sy = std::sin(yAngle_);
+        // third column of RotateY * RotateX (row-major mat4, template/precomp.h:875-876)
+        desc_.lookfrom[0] = sy * cx * dist_ + desc_.lookat[0];
+        desc_.lookfrom[1] = -sx * dist_ + desc_.lookat[1];
+        desc_.lookfrom[2] = cy * cx * dist_ + desc_.lookat[2];
+        return desc_;
+    }
+    const CameraDesc& desc() const { return desc_; }
+    float xAngle() const { return xAngle_; }
+    float yAngle() const { return yAngle_; }
+
+private:
+    CameraDesc desc_;
+    float dist_, xAngle_, yAngle_;
 };
 
 struct DisneyMaterial {

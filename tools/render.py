@@ -6,25 +6,12 @@
 """
 import argparse
 import os
-import struct
 import sys
 import time
-import zlib
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import ag_pathtracer_amd as ag  # noqa: E402
-
-
-def write_png(path, rgb):
-    h, w, _ = rgb.shape
-    raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(h))
-
-    def chunk(tag, data):
-        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
-    with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
-                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
 def main():
@@ -34,6 +21,7 @@ def main():
     ap.add_argument("--height", type=int, default=540)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--out", default="gpurun_out/render.png")
+    ap.add_argument("--pfm", default=None, help="also write the linear float image")
     a = ap.parse_args()
     W, H = a.width, a.height
     aspect = W / float(H)
@@ -50,10 +38,11 @@ def main():
     t0 = time.time()
     st = ag.PathTracer(5).render(scene, W, H, a.spp, ptr)
     dt = time.time() - t0
-    packed = ctx.resolve(ptr, W * H, a.spp).reshape(H, W)
-    rgb = np.stack([(packed >> 16) & 255, (packed >> 8) & 255, packed & 255], -1).astype(np.uint8)
+    packed = ctx.resolve(ptr, W * H, a.spp)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
-    write_png(a.out, rgb)
+    ag.binding.write_png(a.out, packed, W, H)
+    if a.pfm:
+        ag.binding.write_pfm(a.pfm, ctx.download(ptr, (H, W, 4)), a.spp)
     print("%s: %dx%d @%d spp, %d tris, %.2f s, %.1f Mrays/s -> %s" % (desc.name, W, H, a.spp, desc.n_tris, dt, st.rays / dt / 1e6, a.out))
 
 
