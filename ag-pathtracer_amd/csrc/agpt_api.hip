@@ -76,7 +76,6 @@ struct agpt_ctx {
     uint32_t* host_pinned = nullptr;
     int blocks_per_cu = 4;       // AGPT_BLOCKS_PER_CU
     int refill = AGPT_REFILL;    // AGPT_REFILL: idle lanes that trigger an in-flight refill
-    int vote[3] = {1, 1, 1};     // AGPT_VOTE=a,b,c: phase weights of the trace kernel's vote scheduler (tuning)
     bool mis_closest = false;    // AGPT_MIS_CLOSEST=1: trace MIS rays as full closest-hit queries (A/B, tests)
     bool force_generic = false;  // AGPT_FORCE_GENERIC=1: always use the generic k_trace (tests)
     // per-launch HIP-event timing of the trace kernels (agpt_render_params::enable_timing)
@@ -98,6 +97,7 @@ struct agpt_scene {
     bool committed = false;
     int max_depth = 0;
     DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade;
+    DevBuf<uint32_t> d_bigleaves;
     DevBuf<DevPrim> d_prims;
     DevBuf<DevMaterial> d_materials;
     DevBuf<DevLight> d_lights;
@@ -129,7 +129,7 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
     if (use_fast_trace(c, sc, count))
         hipLaunchKernelGGL((k_trace_fast<MODE>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
-                           hits, occ, c->counters.p, c->refill, c->vote[0], c->vote[1], c->vote[2]);
+                           hits, occ, c->counters.p, c->refill);
     else if (sc.max_depth > AGPT_STACK_DEPTH) {
         dim3 grid_deep(c->num_cus * 2);
         if (count)
@@ -192,7 +192,6 @@ int agpt_init(int device, agpt_ctx** out) {
     if (const char* mc = getenv("AGPT_MIS_CLOSEST")) c->mis_closest = mc[0] == '1';
     if (const char* bp = getenv("AGPT_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(bp));
     if (const char* rf = getenv("AGPT_REFILL")) c->refill = std::min(64, std::max(1, atoi(rf)));
-    if (const char* vt = getenv("AGPT_VOTE")) sscanf(vt, "%d:%d:%d", &c->vote[0], &c->vote[1], &c->vote[2]);
     *out = c.release();
     return AGPT_OK;
 }
@@ -240,6 +239,7 @@ void agpt_scene_destroy(agpt_scene* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipDeviceSynchronize();
     s->d_nodes.release();
+    s->d_bigleaves.release();
     s->d_tri_verts.release();
     s->d_tri_shade.release();
     s->d_prims.release();
@@ -406,6 +406,8 @@ int agpt_scene_commit(agpt_scene* s) {
     hipStream_t st = s->ctx->stream;
     int rc;
     if ((rc = upload(s->d_nodes, flat.nodes, st))) return rc;
+    if (flat.bigleaves.empty()) flat.bigleaves.assign(2, 0u);
+    if ((rc = upload(s->d_bigleaves, flat.bigleaves, st))) return rc;
     if ((rc = upload(s->d_tri_verts, flat.tri_verts, st))) return rc;
     if ((rc = upload(s->d_tri_shade, flat.tri_shade, st))) return rc;
     if ((rc = upload(s->d_prims, flat.prims, st))) return rc;
@@ -432,6 +434,7 @@ int agpt_scene_commit(agpt_scene* s) {
     HIP_TRY(hipStreamSynchronize(st));
     s->dev.envs = s->d_envs.p;
     s->dev.nodes = s->d_nodes.p;
+    s->dev.bigleaves = s->d_bigleaves.p;
     s->dev.tri_verts = s->d_tri_verts.p;
     s->dev.tri_shade = s->d_tri_shade.p;
     s->dev.prims = s->d_prims.p;
@@ -712,6 +715,18 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         DevCounters dc;
         HIP_TRY(hipMemcpy(&dc, c->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
         read_counters(dc, stats);
+#ifdef AGPT_TRACE_STATS
+        {
+            const unsigned long long* d = dc.dbg;
+            const double steps = (double)(d[0] + d[1] + d[2]);
+            std::fprintf(stderr,
+                         "[trace stats] steps A/B/C %.3g/%.3g/%.3g (%.1f%%/%.1f%%/%.1f%%)  lanes per step A %.1f B %.1f C %.1f  "
+                         "active lanes per step %.1f  refills %.3g (%.1f lanes each)  prefilter batches %.3g\n",
+                         (double)d[0], (double)d[1], (double)d[2], 100 * d[0] / steps, 100 * d[1] / steps, 100 * d[2] / steps,
+                         d[0] ? (double)d[3] / d[0] : 0., d[1] ? (double)d[4] / d[1] : 0., d[2] ? (double)d[5] / d[2] : 0.,
+                         (double)d[6] / steps, (double)d[7], d[7] ? (double)d[8] / d[7] : 0., (double)d[9]);
+        }
+#endif
         stats->samples = (uint64_t)NP * (uint64_t)rp->spp_count;
         stats->iterations = iterations;
         stats->trace_launches = launches;

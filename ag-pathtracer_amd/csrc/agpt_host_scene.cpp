@@ -370,6 +370,7 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
     out.tri_verts.clear();
     out.tri_shade.clear();
     out.prims.clear();
+    out.bigleaves.clear();
     out.max_depth = 0;
     size_t node_base = 0, tri_base = 0;
     std::vector<size_t> mesh_node_base(meshes.size()), mesh_tri_base(meshes.size());
@@ -424,8 +425,11 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
             if (n.count > 0) {
                 if (n.count <= 7 && first < 0x10000000u)
                     z = AGPT_ENC_LEAF | ((uint32_t)(n.count - 1) << 28) | first;
-                else
-                    w |= AGPT_NODE_BIGLEAF;
+                else {
+                    z = AGPT_ENC_BIGLEAF | (uint32_t)out.bigleaves.size();
+                    out.bigleaves.push_back(first);
+                    out.bigleaves.push_back((uint32_t)n.count);
+                }
             }
             // sibling pairs (node indices 2k, 2k+1) share one 64-B record with the two boxes interleaved component by
             // component, so a lane's four 16-B loads land as (left, right) register pairs for packed-fp32 slab maths:
@@ -448,8 +452,11 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
                 dp.root_enc = first;
             else if (r.count <= 7 && first < 0x10000000u)
                 dp.root_enc = AGPT_ENC_LEAF | ((uint32_t)(r.count - 1) << 28) | first;
-            else
-                dp.root_enc = AGPT_ENC_BIGLEAF | (uint32_t)nb;
+            else {
+                dp.root_enc = AGPT_ENC_BIGLEAF | (uint32_t)(out.bigleaves.size() / 2);
+                out.bigleaves.push_back(first);
+                out.bigleaves.push_back((uint32_t)r.count);
+            }
         }
         // triangles
         const bool has_uv = !mesh.texcoords.empty();

@@ -65,6 +65,7 @@ DevCamera make_camera(const agpt_camera_desc& d);
 struct FlatScene {
     std::vector<float4> nodes, tri_verts, tri_shade;
     std::vector<DevPrim> prims;
+    std::vector<uint32_t> bigleaves;  // (first slot, count) pairs of leaves too big for the inline encoding
     int max_depth = 0;
 };
 // per-mesh concatenation + per-triangle precomputation (trianglemesh.cpp:46-111's ray-independent part)

@@ -75,7 +75,15 @@ __device__ __forceinline__ void pixel_of(const RenderConsts& rc, uint32_t p, int
 
 struct DevCounters {
     unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples, roots;
+#ifdef AGPT_TRACE_STATS
+    unsigned long long dbg[16];  // developer build only: wave-step statistics of k_trace_fast (tools/build_variant.py)
+#endif
 };
+#ifdef AGPT_TRACE_STATS
+#define TS(...) __VA_ARGS__
+#else
+#define TS(...)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // wave-aggregated queue append: one atomic per wave, order inside the wave preserved
@@ -176,8 +184,7 @@ template <int MODE>
 __global__ void __launch_bounds__(AGPT_BLOCK)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-             DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters,
-             int refill, int vote_a, int vote_b, int vote_c) {
+             DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters, int refill) {
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
     __shared__ uint32_t s_stack[AGPT_STACK_DEPTH * AGPT_BLOCK];
@@ -212,9 +219,12 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     // Refills draw from ONE moving queue frontier (one atomic per refill): at any moment the whole chip traces rays
     // that are neighbours in the queue (neighbouring pixels / path ids), which keeps their BVH nodes hot in the L2s.
     // Reserving large private ranges per wave instead measured 8 % slower (A/B on MI355X, same process).
-    bool active = false, in_mesh = false;
+    // A lane's scheduling state is carried by `cur` itself: CUR_IDLE = no ray, CUR_PICK = between meshes (state A),
+    // anything below = an interior child-pair index (state B), sign bit set = a leaf encoding (state C).  One v_cmp per
+    // state gives the wave's vote masks.
+    constexpr uint32_t CUR_IDLE = 0x7FFFFFFFu, CUR_PICK = 0x7FFFFFFEu;
     bool exhausted = false;  // wave-uniform
-    uint32_t pid = 0, cur = 0, hid = AGPT_HIT_MISS;
+    uint32_t pid = 0, cur = CUR_IDLE, hid = AGPT_HIT_MISS;
     int sp = 0;
     float rayt = 0.f, hb1 = 0.f, hb2 = 0.f;
     unsigned long long mask = 0;
@@ -233,13 +243,15 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     int mis_skip = -1;        // MODE 2: primitive index of the sampled area light's sphere (never a blocker itself)
     bool mis_reach = true;    // MODE 2: infinite light, or the ray reaches the light's sphere
     bool any_slow = false;                  // wave-uniform: some active lane's ray needs the true-division slab test
+    TS(unsigned long long ts_steps[3] = {0, 0, 0}; unsigned long long ts_lanes[3] = {0, 0, 0}; unsigned long long ts_act = 0;
+       unsigned long long ts_refills = 0; unsigned long long ts_refilled = 0; unsigned long long ts_pref = 0;)
 
     for (;;) {
         // ---- refill ---------------------------------------------------------------------------------------
-        unsigned long long act = __ballot(active);
-        int n_active = __popcll(act);
-        if (n_active <= 64 - refill && !(exhausted && ring_head == ring_tail)) {
-            const uint32_t n_idle = (uint32_t)(64 - n_active);
+        unsigned long long act = __ballot(cur != CUR_IDLE);
+        const int n_active0 = __popcll(act);
+        if (n_active0 <= 64 - refill && !(exhausted && ring_head == ring_tail)) {
+            const uint32_t n_idle = (uint32_t)(64 - n_active0);
             // top the ring up from the single global queue frontier: phase A runs for 64 NEW rays with all lanes busy
             while (ring_tail - ring_head < n_idle && !exhausted) {
                 uint32_t base = 0;
@@ -290,6 +302,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     ring_mask[slot] = (nr.fast ? m : all_prims) & ~skip_bit;
                 }
                 ring_tail += n_new;
+                TS(ts_pref++;)
             }
             // hand ring entries to idle lanes (same wave wrote them: a wave barrier orders the LDS writes and reads)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -297,7 +310,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t avail = ring_tail - ring_head;
             const uint32_t take = n_idle < avail ? n_idle : avail;
-            if (!active) {
+            if (cur == CUR_IDLE) {
                 const uint32_t rank = (uint32_t)__popcll(~act & lt_mask);
                 if (rank < take) {
                     const uint32_t slot = (ring_head + rank) & (AGPT_RING - 1);
@@ -321,14 +334,14 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     hid = AGPT_HIT_MISS;
                     hb1 = 0.f;
                     hb2 = 0.f;
-                    in_mesh = false;
                     sp = 0;
-                    active = true;
+                    cur = CUR_PICK;
                 }
             }
             ring_head += take;
-            act = __ballot(active);
-            any_slow = __ballot(active && !r.fast) != 0;
+            TS(ts_refills++; ts_refilled += take;)
+            act = __ballot(cur != CUR_IDLE);
+            any_slow = __ballot(cur != CUR_IDLE && !r.fast) != 0;
         }
         if (act == 0) break;
 
@@ -338,12 +351,14 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         // body cost); a lane's own sequence of operations is the reference's, only the interleaving between lanes
         // changes.  (A while-while loop makes every lane wait for the longest descent in the wave: 37 % active lanes.)
         for (;;) {
-            const bool wantA = active && !in_mesh;
-            const bool wantB = active && in_mesh && !(cur & AGPT_ENC_LEAF);
-            const bool wantC = active && in_mesh && (cur & AGPT_ENC_LEAF);
-            const int nA = __popcll(__ballot(wantA)), nB = __popcll(__ballot(wantB)), nC = __popcll(__ballot(wantC));
-            if (nB * vote_b >= nA * vote_a && nB * vote_b >= nC * vote_c) {
-                if (wantB) {
+            const int nA = __popcll(__ballot(cur == CUR_PICK)), nB = __popcll(__ballot(cur < CUR_PICK)),
+                      nC = __popcll(__ballot((int32_t)cur < 0));
+            const int n_active = nA + nB + nC;
+            if (n_active == 0 || (n_active <= 64 - refill && !(exhausted && ring_head == ring_tail))) break;
+            TS(ts_act += (unsigned long long)n_active; if (!(nB >= nA && nB >= nC) && !(nC >= nA)) { ts_steps[0]++; ts_lanes[0] += nA; })
+            if (nB >= nA && nB >= nC) {
+                TS(ts_steps[1]++; ts_lanes[1] += nB;)
+                if (cur < CUR_PICK) {
                     const NodePair np = load_pair(sc, cur);
                     float dl, dr;
                     bool hl, hr;
@@ -351,8 +366,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
                         if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
                     }
-                    uint32_t encl = encode_child(cur, __float_as_uint(np.n3.x), __float_as_uint(np.n3.z));
-                    uint32_t encr = encode_child(cur + 1, __float_as_uint(np.n3.y), __float_as_uint(np.n3.w));
+                    const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
                     if (hl && hr) {
                         bool swap = ANY ? false : (dr < dl);
                         stack[sp * AGPT_BLOCK] = swap ? encl : encr;
@@ -363,22 +377,17 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     } else if (hr) {
                         cur = encr;
                     } else if (sp == 0) {
-                        in_mesh = false;
+                        cur = CUR_PICK;
                     } else {
                         sp--;
                         cur = stack[sp * AGPT_BLOCK];
                     }
                 }
-            } else if (nC * vote_c >= nA * vote_a) {
-                if (wantC) {
+            } else if (nC >= nA) {
+                TS(ts_steps[2]++; ts_lanes[2] += nC;)
+                if ((int32_t)cur < 0) {
                     uint32_t first, cnt;
-                    if ((cur & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
-                        node_words(sc, cur & 0x0FFFFFFFu, first, cnt);
-                        cnt &= ~AGPT_NODE_BIGLEAF;
-                    } else {
-                        first = cur & 0x0FFFFFFFu;
-                        cnt = ((cur >> 28) & 7u) + 1u;
-                    }
+                    leaf_range(sc, cur, first, cnt);
                     bool done = false;
                     for (uint32_t i = 0; i < cnt; ++i) {
                         const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
@@ -403,15 +412,15 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                     if (ANY && done) {
                         occluded[pid] = MIS ? 0u : 1u;   // MODE 2 writes "ok" (1 = add the BSDF-leg contribution)
-                        active = false;
+                        cur = CUR_IDLE;
                     } else if (sp == 0) {
-                        in_mesh = false;
+                        cur = CUR_PICK;
                     } else {
                         sp--;
                         cur = stack[sp * AGPT_BLOCK];
                     }
                 }
-            } else if (wantA) {
+            } else if (cur == CUR_PICK) {
                 // next primitive of this lane's mask (list order), or retire
                 if (mask == 0) {
                     if (MIS)
@@ -426,7 +435,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         h.b2 = hb2;
                         hits[pid] = h;
                     }
-                    active = false;
+                    cur = CUR_IDLE;
                 } else {
                     const int k = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -439,11 +448,11 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                                 const bool tie_loses = pa.w == 1.f && mis_skip >= 0 && mis_reach && k < mis_skip && root == rayt;
                                 if (!tie_loses) {
                                     occluded[pid] = 0u;
-                                    active = false;
+                                    cur = CUR_IDLE;
                                 }
                             } else if (ANY) {
                                 occluded[pid] = 1u;
-                                active = false;
+                                cur = CUR_IDLE;
                             } else {
                                 rayt = root;
                                 hid = AGPT_HIT_SPHERE | (uint32_t)k;
@@ -456,16 +465,17 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         if (box_test(pa.x, pa.y, pa.z, pb2.x, pb2.y, pb2.z, r, rayt, dist)) {
                             cur = __float_as_uint(pb2.w);
                             sp = 0;
-                            in_mesh = true;
                         }
                     }
                 }
             }
-            act = __ballot(active);
-            if (act == 0) break;
-            if (__popcll(act) <= 64 - refill && !(exhausted && ring_head == ring_tail)) break;
         }
     }
+    TS(if (lane == 0) {
+        unsigned long long* d = counters->dbg + 0;
+        for (int k = 0; k < 3; ++k) { atomicAdd(d + k, ts_steps[k]); atomicAdd(d + 3 + k, ts_lanes[k]); }
+        atomicAdd(d + 6, ts_act); atomicAdd(d + 7, ts_refills); atomicAdd(d + 8, ts_refilled); atomicAdd(d + 9, ts_pref);
+    })
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (MODE == 1)
             atomicAdd(&counters->anyhit_rays, (unsigned long long)count);
@@ -816,7 +826,12 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 // writes its path id at its (order-preserving) offset -- 4 atomics per 1024 paths instead of 4 per wave: same-line
 // atomics serialise at ~11 ns each and were the kernel's bottleneck.
 #define SHADE_U 4
-__global__ void __launch_bounds__(AGPT_BLOCK)
+// 3 waves/SIMD: the register allocator is capped at 168 VGPRs (48 spilled to scratch); measured 127 ms per C3 step
+// against 140 ms at 2 waves (217 VGPRs, no spills) and 151 ms at 4 waves (96 spilled).
+#ifndef AGPT_SHADE_WAVES
+#define AGPT_SHADE_WAVES 3
+#endif
+__global__ void __launch_bounds__(AGPT_BLOCK, AGPT_SHADE_WAVES)
 k_shade(DevScene sc, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout, DevCounters* __restrict__ counters) {
     __shared__ uint32_t s_pid[SHADE_U][AGPT_BLOCK];
     __shared__ uint32_t s_bits[SHADE_U][AGPT_BLOCK];

@@ -5,9 +5,10 @@
 //                           SIBLING PAIR: nodes 2k and 2k+1 (always fetched together, bvhtrimesh.h:350-351) share one
 //                           64-B line with their boxes interleaved component-wise --
 //                             [4k+0] lx0 rx0 ly0 ry0  [4k+1] lz0 rz0 lx1 rx1  [4k+2] ly1 ry1 lz1 rz1  [4k+3] zL zR wL wR
-//                           z = the node's precomputed traversal encoding (interior: child-pair index, leaf:
-//                           flag|count-1|first slot), w = count | AGPT_NODE_BIGLEAF; all meshes concatenated,
-//                           indices rebased to global node / triangle-slot indices
+//                           z = the node's precomputed traversal encoding (interior: child-pair index; leaf:
+//                           AGPT_ENC_LEAF|count-1|first slot; leaf with > 7 primitives: AGPT_ENC_BIGLEAF|k, with
+//                           (first, count) in bigleaves[2k..]), w = count; all meshes concatenated, indices rebased
+//                           to global node / triangle-slot indices
 //   tri_verts  float4[3*T]  per REORDERED primitive slot (BVH leaf order): v0,v1,v2; v0.w = global triangle id,
 //                           v1.w = flags (bit0: degenerate-reject, quirk 11), v2.w unused.  Replaces the reference's
 //                           primitives[] -> indices[] -> vertices[] double indirection (88 B/test -> 48 B/test)
@@ -38,7 +39,6 @@
 // leaf with more prims (identical centroids, bvhtrimesh.h:235-238): 0xF0000000 | node index (node is re-fetched).
 #define AGPT_ENC_LEAF 0x80000000u
 #define AGPT_ENC_BIGLEAF 0xF0000000u
-#define AGPT_NODE_BIGLEAF 0x80000000u  // flag in a node record's count word: leaf too big for the inline encoding
 
 struct DevPrim {
     int32_t type;
@@ -90,6 +90,7 @@ struct DevCamera {
 
 struct DevScene {
     const float4* nodes;
+    const uint32_t* bigleaves;  // (first, count) pairs, see above
     const float4* tri_verts;
     const float4* tri_shade;
     const DevPrim* prims;

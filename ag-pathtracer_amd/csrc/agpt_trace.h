@@ -116,11 +116,16 @@ __device__ __forceinline__ void pair_boxes_exact(const NodePair& p, const TraceR
     hl = box_test_t<false>(p.n0.x, p.n0.z, p.n1.x, p.n1.z, p.n2.x, p.n2.z, r, rayt, dl);
     hr = box_test_t<false>(p.n0.y, p.n0.w, p.n1.y, p.n1.w, p.n2.y, p.n2.w, r, rayt, dr);
 }
-// z / w words (traversal encoding, count | flags) of ONE node of the interleaved array
-__device__ __forceinline__ void node_words(const DevScene& sc, uint32_t node, uint32_t& z, uint32_t& w) {
-    const uint32_t* rec = reinterpret_cast<const uint32_t*>(sc.nodes + 4 * (size_t)(node >> 1));
-    z = rec[12 + (node & 1)];
-    w = rec[14 + (node & 1)];
+// (first slot, count) of a leaf from its traversal encoding
+__device__ __forceinline__ void leaf_range(const DevScene& sc, uint32_t enc, uint32_t& first, uint32_t& count) {
+    if ((enc & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
+        const uint32_t k = enc & 0x0FFFFFFFu;
+        first = sc.bigleaves[2 * k];
+        count = sc.bigleaves[2 * k + 1];
+    } else {
+        first = enc & 0x0FFFFFFFu;
+        count = ((enc >> 28) & 7u) + 1u;
+    }
 }
 
 __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
@@ -188,11 +193,6 @@ __device__ __forceinline__ bool analytic_test(float kind, v3 a, float bx, float 
 __device__ __forceinline__ bool sphere_test(const DevPrim& P, const TraceRay& r, float rayt, float& root_out) {
     if (P.type == AGPT_PRIM_PLANE) return plane_test_c(V3(P.cx, P.cy, P.cz), P.r, P.r2, r, rayt, root_out);
     return sphere_test_c(V3(P.cx, P.cy, P.cz), P.r2, r, rayt, root_out);
-}
-
-// traversal encoding of a child from its node record's last two words (precomputed on the host, agpt_scene.h)
-__device__ __forceinline__ uint32_t encode_child(uint32_t node_index, uint32_t z, uint32_t w) {
-    return (w & AGPT_NODE_BIGLEAF) ? (AGPT_ENC_BIGLEAF | node_index) : z;
 }
 
 struct TraceCounters {
@@ -287,8 +287,7 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
                     pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
                 else
                     pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
-                uint32_t encl = encode_child(cur, __float_as_uint(np.n3.x), __float_as_uint(np.n3.z));
-                uint32_t encr = encode_child(cur + 1, __float_as_uint(np.n3.y), __float_as_uint(np.n3.w));
+                const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
                 if (hl && hr) {
                     bool swap = ANY ? false : (dr < dl);
                     uint32_t nearn = swap ? encr : encl;
@@ -306,13 +305,7 @@ __device__ __forceinline__ bool trace_scene(const DevScene& sc, v3 O, v3 D, floa
                 }
             } else {
                 uint32_t first, count;
-                if ((cur & AGPT_ENC_BIGLEAF) == AGPT_ENC_BIGLEAF) {
-                    node_words(sc, cur & 0x0FFFFFFFu, first, count);
-                    count &= ~AGPT_NODE_BIGLEAF;
-                } else {
-                    first = cur & 0x0FFFFFFFu;
-                    count = ((cur >> 28) & 7u) + 1u;
-                }
+                leaf_range(sc, cur, first, count);
                 for (uint32_t i = 0; i < count; ++i) {
                     const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
                     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
