@@ -445,6 +445,8 @@ int agpt_scene_commit(agpt_scene* s) {
     s->dev.n_materials = (int)s->materials.size();
     s->dev.n_infinite = n_inf;
     s->dev.max_depth = flat.max_depth;
+    s->dev.rootpair_base = flat.rootpair_base;
+    s->dev.mesh_mask = flat.mesh_mask;
     s->dev.n_meshes = 0;
     for (const DevPrim& dp : flat.prims)
         if (dp.type == AGPT_PRIM_MESH && dp.n_tris > 0) s->dev.n_meshes++;
@@ -716,12 +718,13 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         HIP_TRY(hipMemcpy(&dc, c->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
         read_counters(dc, stats);
 #ifdef AGPT_TRACE_STATS
-        {
-            const unsigned long long* d = dc.dbg;
+        for (int mode = 0; mode < 3; ++mode) {
+            const unsigned long long* d = dc.dbg + 16 * mode;
             const double steps = (double)(d[0] + d[1] + d[2]);
+            if (steps == 0) continue;
             std::fprintf(stderr,
-                         "[trace stats] steps A/B/C %.3g/%.3g/%.3g (%.1f%%/%.1f%%/%.1f%%)  lanes per step A %.1f B %.1f C %.1f  "
-                         "active lanes per step %.1f  refills %.3g (%.1f lanes each)  prefilter batches %.3g\n",
+                         "[trace stats mode %d] steps A/B/C %.3g/%.3g/%.3g (%.1f%%/%.1f%%/%.1f%%)  lanes per step A %.1f B %.1f C %.1f  "
+                         "active lanes per step %.1f  refills %.3g (%.1f lanes each)  prefilter batches %.3g\n", mode,
                          (double)d[0], (double)d[1], (double)d[2], 100 * d[0] / steps, 100 * d[1] / steps, 100 * d[2] / steps,
                          d[0] ? (double)d[3] / d[0] : 0., d[1] ? (double)d[4] / d[1] : 0., d[2] ? (double)d[5] / d[2] : 0.,
                          (double)d[6] / steps, (double)d[7], d[7] ? (double)d[8] / d[7] : 0., (double)d[9]);

@@ -76,7 +76,7 @@ __device__ __forceinline__ void pixel_of(const RenderConsts& rc, uint32_t p, int
 struct DevCounters {
     unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples, roots;
 #ifdef AGPT_TRACE_STATS
-    unsigned long long dbg[16];  // developer build only: wave-step statistics of k_trace_fast (tools/build_variant.py)
+    unsigned long long dbg[48];  // developer build only: wave-step statistics of k_trace_fast (tools/build_variant.py)
 #endif
 };
 #ifdef AGPT_TRACE_STATS
@@ -223,6 +223,19 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     // anything below = an interior child-pair index (state B), sign bit set = a leaf encoding (state C).  One v_cmp per
     // state gives the wave's vote masks.
     constexpr uint32_t CUR_IDLE = 0x7FFFFFFFu, CUR_PICK = 0x7FFFFFFEu;
+    const uint32_t rootpair_base = sc.rootpair_base;
+    const unsigned long long mesh_mask = sc.mesh_mask;
+    // Scene::Intersect's walk to the next primitive of the list (scene.h:8-17).  A mesh is entered through its root
+    // pair -- the root-box test becomes the lane's next interior step (state B); spheres, planes and the end of the
+    // list go through state A.
+    auto pick_next = [&](unsigned long long& m) -> uint32_t {
+        const unsigned long long low = m & (0ull - m);
+        if (low & mesh_mask) {
+            m ^= low;
+            return rootpair_base + 2u * (uint32_t)(__ffsll((long long)low) - 1);
+        }
+        return CUR_PICK;
+    };
     bool exhausted = false;  // wave-uniform
     uint32_t pid = 0, cur = CUR_IDLE, hid = AGPT_HIT_MISS;
     int sp = 0;
@@ -335,7 +348,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     hb1 = 0.f;
                     hb2 = 0.f;
                     sp = 0;
-                    cur = CUR_PICK;
+                    cur = pick_next(mask);
                 }
             }
             ring_head += take;
@@ -367,6 +380,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
                     }
                     const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
+                    hr = hr && cur < rootpair_base;   // a root pair has no right child
                     if (hl && hr) {
                         bool swap = ANY ? false : (dr < dl);
                         stack[sp * AGPT_BLOCK] = swap ? encl : encr;
@@ -377,7 +391,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     } else if (hr) {
                         cur = encr;
                     } else if (sp == 0) {
-                        cur = CUR_PICK;
+                        cur = pick_next(mask);
                     } else {
                         sp--;
                         cur = stack[sp * AGPT_BLOCK];
@@ -414,14 +428,14 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         occluded[pid] = MIS ? 0u : 1u;   // MODE 2 writes "ok" (1 = add the BSDF-leg contribution)
                         cur = CUR_IDLE;
                     } else if (sp == 0) {
-                        cur = CUR_PICK;
+                        cur = pick_next(mask);
                     } else {
                         sp--;
                         cur = stack[sp * AGPT_BLOCK];
                     }
                 }
             } else if (cur == CUR_PICK) {
-                // next primitive of this lane's mask (list order), or retire
+                // end of the primitive list (retire), or the sphere / plane that is next in list order
                 if (mask == 0) {
                     if (MIS)
                         occluded[pid] = mis_reach ? 1u : 0u;
@@ -460,19 +474,14 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                                 hb2 = 0.f;
                             }
                         }
-                    } else if (pa.w == 0.f) {
-                        float dist;
-                        if (box_test(pa.x, pa.y, pa.z, pb2.x, pb2.y, pb2.z, r, rayt, dist)) {
-                            cur = __float_as_uint(pb2.w);
-                            sp = 0;
-                        }
                     }
+                    if (cur == CUR_PICK) cur = pick_next(mask);   // (meshes never get here: pick_next routes them to B)
                 }
             }
         }
     }
     TS(if (lane == 0) {
-        unsigned long long* d = counters->dbg + 0;
+        unsigned long long* d = counters->dbg + 16 * MODE;
         for (int k = 0; k < 3; ++k) { atomicAdd(d + k, ts_steps[k]); atomicAdd(d + 3 + k, ts_lanes[k]); }
         atomicAdd(d + 6, ts_act); atomicAdd(d + 7, ts_refills); atomicAdd(d + 8, ts_refilled); atomicAdd(d + 9, ts_pref);
     })

@@ -101,6 +101,12 @@ struct DevScene {
     int32_t n_infinite;        // number of IsInfinite() lights
     int32_t n_meshes;          // non-empty mesh primitives
     int32_t max_depth;         // deepest BVH of the scene (selects the traversal-stack size)
+    // Root pairs: for each of the first 64 primitives that is a non-empty mesh, nodes[] holds one extra pair record at
+    // node index rootpair_base + 2k whose LEFT box is the mesh's root box and whose encoding is the mesh's root -- the
+    // reference's root-box test at BVHTriMesh::Intersect (bvhtrimesh.h:187,195) then runs as an ordinary interior step
+    // of the traversal kernel (the right half of the record is ignored).  mesh_mask: bit k set for those primitives.
+    uint32_t rootpair_base;
+    unsigned long long mesh_mask;
     DevCamera cam;
 };
 
