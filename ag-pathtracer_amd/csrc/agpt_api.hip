@@ -589,7 +589,7 @@ int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* o
     HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * sizeof(agpt_hit)));
     HIP_TRY(hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(agpt_ray), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
-    HIP_TRY(hipMemsetAsync(c->work.p, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->work.p, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
     int blocks = (n + AGPT_BLOCK - 1) / AGPT_BLOCK;
     hipLaunchKernelGGL(k_prepare_rays, dim3(blocks), dim3(AGPT_BLOCK), 0, c->stream, d_rays, n, c->ext_o.p, c->ext_d.p);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -694,13 +694,13 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
             }
             const int nxt = cur ^ 1;
             HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
-            HIP_TRY(hipMemsetAsync(c->work.p, 0, 96 * sizeof(uint32_t), c->stream));
+            HIP_TRY(hipMemsetAsync(c->work.p, 0, 3 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
             launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
             if (mis_mode)
-                launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + 32, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
+                launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
             else
-                launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + 32, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
-            launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 64, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+                launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
+            launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
             hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
             cur = nxt;
             iterations++;

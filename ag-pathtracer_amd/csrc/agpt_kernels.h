@@ -40,6 +40,7 @@ struct PathBuffers {
 };
 
 #define AGPT_QSTRIDE 32  // queue counters live on separate 128-B lines: same-line atomics serialise (~11 ns each)
+#define AGPT_FRONTIERS 8u // work-queue frontiers per trace launch (one per XCD), AGPT_QSTRIDE words apart
 struct Queues {
     uint32_t *active, *ext, *mis, *shadow;   // path ids
     uint32_t* counts;                        // [q * AGPT_QSTRIDE]: q = 0 active, 1 ext, 2 mis, 3 shadow
@@ -237,6 +238,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         return CUR_PICK;
     };
     bool exhausted = false;  // wave-uniform
+    uint32_t seg = blockIdx.x & (AGPT_FRONTIERS - 1u), segs_left = AGPT_FRONTIERS;   // wave-uniform
+    const uint32_t seg_len = ((count + AGPT_FRONTIERS - 1u) / AGPT_FRONTIERS + 63u) & ~63u;
     uint32_t pid = 0, cur = CUR_IDLE, hid = AGPT_HIT_MISS;
     int sp = 0;
     float rayt = 0.f, hb1 = 0.f, hb2 = 0.f;
@@ -267,11 +270,29 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             const uint32_t n_idle = (uint32_t)(64 - n_active0);
             // top the ring up from the single global queue frontier: phase A runs for 64 NEW rays with all lanes busy
             while (ring_tail - ring_head < n_idle && !exhausted) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_head, 64u);
-                base = __shfl(base, 0);
-                if (base + 64u >= count) exhausted = true;
-                const uint32_t n_new = base < count ? (count - base < 64u ? count - base : 64u) : 0u;
+                // The queue is cut into AGPT_FRONTIERS contiguous segments, each with its own frontier counter on its own
+                // 128-B line; a wave starts in the segment of its XCD (workgroups are dealt round-robin to the 8 XCDs) and
+                // moves on to the next segment when its own is drained.  One shared counter was the limit of the any-hit
+                // launches: same-address atomics complete one per ~11 ns chip-wide, 7.8 M of them per launch set = 86 ms.
+                // Per-XCD frontiers also keep every L2 on its own neighbourhood of the queue.
+                uint32_t base = 0, n_new = 0;
+                for (;;) {
+                    const uint32_t seg_begin = seg * seg_len;
+                    const uint32_t seg_end = seg_begin + seg_len < count ? seg_begin + seg_len : count;
+                    uint32_t off = 0;
+                    if (lane == 0) off = atomicAdd(work_head + seg * AGPT_QSTRIDE, 64u);
+                    off = __shfl(off, 0);
+                    if (seg_begin < seg_end && off < seg_end - seg_begin) {
+                        base = seg_begin + off;
+                        n_new = seg_end - base < 64u ? seg_end - base : 64u;
+                        break;
+                    }
+                    if (--segs_left == 0) {
+                        exhausted = true;
+                        break;
+                    }
+                    seg = (seg + 1u) & (AGPT_FRONTIERS - 1u);
+                }
                 if ((uint32_t)lane < n_new) {
                     const uint32_t npid = queue ? queue[base + lane] : base + lane;
                     float4 o = ray_o[npid];
@@ -336,6 +357,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         mis_skip = -1;
                         mis_reach = true;
                         const DevLight& lt = sc.lights[__float_as_uint(d.w)];
+#ifndef AGPT_EXP_NOSPHERE
                         if (lt.type == AGPT_LIGHT_AREA) {
                             const float4 sa = s_prim[2 * lt.shape], sb = s_prim[2 * lt.shape + 1];
                             float ts;
@@ -343,6 +365,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                             mis_reach = sphere_test_c(V3(sa.x, sa.y, sa.z), sb.x, r, rayt, ts);
                             if (mis_reach) rayt = ts;
                         }
+#else
+                        mis_skip = lt.shape;
+#endif
                     }
                     hid = AGPT_HIT_MISS;
                     hb1 = 0.f;
