@@ -75,7 +75,8 @@ struct agpt_ctx {
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
     int blocks_per_cu = 4;       // AGPT_BLOCKS_PER_CU
-    int refill = AGPT_REFILL;    // AGPT_REFILL: idle lanes that trigger an in-flight refill
+    int refill = AGPT_REFILL;    // AGPT_REFILL: idle lanes that trigger an in-flight refill (closest-hit launches)
+    int refill_any = AGPT_REFILL_ANY;  // AGPT_REFILL_ANY: same for the any-hit / MIS-query launches
     bool mis_closest = false;    // AGPT_MIS_CLOSEST=1: trace MIS rays as full closest-hit queries (A/B, tests)
     bool force_generic = false;  // AGPT_FORCE_GENERIC=1: always use the generic k_trace (tests)
     // per-launch HIP-event timing of the trace kernels (agpt_render_params::enable_timing)
@@ -129,7 +130,7 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
     if (use_fast_trace(c, sc, count))
         hipLaunchKernelGGL((k_trace_fast<MODE>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
-                           hits, occ, c->counters.p, c->refill);
+                           hits, occ, c->counters.p, MODE == 0 ? c->refill : c->refill_any);
     else if (sc.max_depth > AGPT_STACK_DEPTH) {
         dim3 grid_deep(c->num_cus * 2);
         if (count)
@@ -192,6 +193,7 @@ int agpt_init(int device, agpt_ctx** out) {
     if (const char* mc = getenv("AGPT_MIS_CLOSEST")) c->mis_closest = mc[0] == '1';
     if (const char* bp = getenv("AGPT_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(bp));
     if (const char* rf = getenv("AGPT_REFILL")) c->refill = std::min(64, std::max(1, atoi(rf)));
+    if (const char* rf = getenv("AGPT_REFILL_ANY")) c->refill_any = std::min(64, std::max(1, atoi(rf)));
     *out = c.release();
     return AGPT_OK;
 }

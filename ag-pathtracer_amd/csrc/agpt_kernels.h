@@ -40,7 +40,9 @@ struct PathBuffers {
 };
 
 #define AGPT_QSTRIDE 32  // queue counters live on separate 128-B lines: same-line atomics serialise (~11 ns each)
-#define AGPT_FRONTIERS 8u // work-queue frontiers per trace launch (one per XCD), AGPT_QSTRIDE words apart
+#ifndef AGPT_FRONTIERS
+#define AGPT_FRONTIERS 8u
+#endif // work-queue frontiers per trace launch (one per XCD), AGPT_QSTRIDE words apart
 struct Queues {
     uint32_t *active, *ext, *mis, *shadow;   // path ids
     uint32_t* counts;                        // [q * AGPT_QSTRIDE]: q = 0 active, 1 ext, 2 mis, 3 shadow
@@ -165,7 +167,8 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 //     processed once all lanes have reached one, then lanes whose mesh is finished pick their next primitive;
 //   * the wave-uniform phase-A filter uses the cheap slab test (b-O)*RN(1/D) with a widened reject margin, which
 //     can only over-accept; the exact Bounds::Intersect is re-run per lane where the reference runs it.
-#define AGPT_REFILL 20
+#define AGPT_REFILL 20      // idle lanes that trigger a refill, closest-hit launches (tuned on C3: 16-24 equal)
+#define AGPT_REFILL_ANY 40  // same, any-hit / MIS-query launches: short traversals, refills are cheaper in bulk
 #define AGPT_RING 128  // entries of the per-wave ring of pre-filtered rays (power of two, >= 64 + 63)
 // per-primitive root record staged in LDS: [2k] = (bmin.xyz | sphere centre.xyz, kind), [2k+1] = (bmax.xyz, root_enc) |
 // (r2, -, -, -) | (half x, half z, -, -); kind 0 = mesh, 1 = sphere, 2 = empty mesh (never hit), 3 = plane
