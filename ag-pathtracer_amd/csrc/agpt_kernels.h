@@ -706,6 +706,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             const DevMaterial& m = sc.materials[sc.prims[s.prim].material];
             Bsdf bsdf;
             bsdf_setup(bsdf, m, s.n, s.ns, s.ss_bsdf);
+            const WoCache wc = bsdf_wo_cache(bsdf, m, s.wo);
             // ---- UniformSampleOneLight / EstimateDirect (integrator.h:38-105) -------------------
             const bool do_nee = !bsdf_is_perfectly_specular(bsdf) && sc.n_lights > 0;
             int numLight = 0;
@@ -759,7 +760,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                 }
                 if (lightPdf > 0 && !isblack(Li)) {  // integrator.h:44-60
                     v3 f;
-                    bsdf_f_pdf(bsdf, m, s.wo, wi, true, &f, &scatteringPdf);
+                    bsdf_f_pdf(bsdf, m, wc, s.wo, wi, true, &f, &scatteringPdf);
                     f = f * absdot(wi, s.ns);
                     if (!isblack(f)) {
                         float weight = power_heuristic(1, lightPdf, 1, scatteringPdf);
@@ -793,7 +794,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                     u1 = rng_float(rng);
                 }
                 bool sampledSpecular = false;
-                v3 f = bsdf_sample_f(bsdf, m, s.wo, &wi, u0, u1, &pdf, leg == 0, &sampledSpecular);
+                v3 f = bsdf_sample_f(bsdf, m, wc, s.wo, &wi, u0, u1, &pdf, leg == 0, &sampledSpecular);
                 if (leg == 0) {
                     const DevLight& light = sc.lights[numLight];
                     f = f * absdot(wi, s.ns);
@@ -985,9 +986,11 @@ __global__ void k_kat_bsdf_eval(DevScene sc, int material, int n, const float* _
     Bsdf b;
     kat_frame(b, m);
     v3 wo = V3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi = V3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
-    v3 f = bsdf_f(b, m, wo, wi, true);
+    v3 f;
+    float pdf;
+    bsdf_f_pdf(b, m, bsdf_wo_cache(b, m, wo), wo, wi, true, &f, &pdf);
     f3o[3 * i] = f.x; f3o[3 * i + 1] = f.y; f3o[3 * i + 2] = f.z;
-    pdfo[i] = bsdf_pdf(b, m, wo, wi, true);
+    pdfo[i] = pdf;
 }
 __global__ void k_kat_bsdf_sample(DevScene sc, int material, int n, const float* __restrict__ wo3, const float* __restrict__ u2,
                                   float* __restrict__ wi3o, float* __restrict__ f3o, float* __restrict__ pdfo,
@@ -1001,7 +1004,7 @@ __global__ void k_kat_bsdf_sample(DevScene sc, int material, int n, const float*
     v3 wi = V3s(0.f);
     float pdf = 0;
     bool spec = false;
-    v3 f = bsdf_sample_f(b, m, wo, &wi, u2[2 * i], u2[2 * i + 1], &pdf, false, &spec);
+    v3 f = bsdf_sample_f(b, m, bsdf_wo_cache(b, m, wo), wo, &wi, u2[2 * i], u2[2 * i + 1], &pdf, false, &spec);
     wi3o[3 * i] = wi.x; wi3o[3 * i + 1] = wi.y; wi3o[3 * i + 2] = wi.z;
     f3o[3 * i] = f.x; f3o[3 * i + 1] = f.y; f3o[3 * i + 2] = f.z;
     pdfo[i] = pdf;

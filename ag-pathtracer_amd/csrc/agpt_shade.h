@@ -144,8 +144,8 @@ __device__ __forceinline__ float tr_lambda(const DevMaterial& m, v3 w) {
 }
 __device__ __forceinline__ float tr_G1(const DevMaterial& m, v3 w) { return 1 / (1 + tr_lambda(m, w)); }
 // MicrofacetDistribution::Pdf microfacet.h:107-109
-__device__ __forceinline__ float tr_pdf(const DevMaterial& m, v3 wo, v3 wh) {
-    return tr_D(m, wh) * tr_G1(m, wo) * absdot(wo, wh) / AbsCosTheta(wo);
+__device__ __forceinline__ float tr_pdf(const DevMaterial& m, v3 wo, v3 wh, float G1o) {  // G1o = tr_G1(m, wo)
+    return tr_D(m, wh) * G1o * absdot(wo, wh) / AbsCosTheta(wo);
 }
 // microfacet.h:180-201
 __device__ __forceinline__ float fr_dielectric(float cosThetaI, float etaI, float etaT) {
@@ -186,16 +186,23 @@ struct LobeEval {
     v3 f;
     float pdf;
 };
+// Values that depend on the outgoing direction only.  One shading point evaluates its BSDF for three (wo, wi) pairs and
+// samples it twice, always with the same wo: G1(wo) (two square roots, three divisions) and the Schlick weight of wo
+// are computed once; the inputs are identical each time, so the shared values are the bits every call would produce.
+struct WoCache {
+    float G1o;  // tr_G1(m, wo)
+    float Fo;   // schlick_weight(AbsCosTheta(wo))
+};
 
 // f(wo,wi) and Pdf(wo,wi) of one lobe in the local frame.  Evaluating both together lets the microfacet lobe share
 // wh, D(wh) and G1(wo) between MicrofacetReflection::f (reflection.h:42-54) and ::Pdf (:67-71): wi+wo and wo+wi, and
 // the two D / G1 calls of the reference, are the same fp32 values, so sharing them does not change a bit.
-__device__ __forceinline__ LobeEval lobe_eval(const DevMaterial& m, int lobe, v3 wo, v3 wi) {
+__device__ __forceinline__ LobeEval lobe_eval(const DevMaterial& m, int lobe, v3 wo, v3 wi, const WoCache& wc) {
     LobeEval e;
     e.f = V3s(0.f);
     e.pdf = 0.f;
     if (lobe == LOBE_DIFFUSE) {  // DisneyDiffuse::f disney.h:28-35; BxDF::Pdf reflection.h:16-18
-        float Fo = schlick_weight(AbsCosTheta(wo)), Fi = schlick_weight(AbsCosTheta(wi));
+        float Fo = wc.Fo, Fi = schlick_weight(AbsCosTheta(wi));
         e.f = mat_v3(m.diffuse_R) * AGPT_INVPI * (1 - Fo / 2) * (1 - Fi / 2);
         e.pdf = same_hemisphere(wo, wi) ? AbsCosTheta(wi) * AGPT_INVPI : 0;
     } else if (lobe == LOBE_RETRO) {  // DisneyRetro::f disney.h:43-55
@@ -204,7 +211,7 @@ __device__ __forceinline__ LobeEval lobe_eval(const DevMaterial& m, int lobe, v3
         if (!(wh.x == 0 && wh.y == 0 && wh.z == 0)) {
             wh = normalize(wh);
             float cosThetaD = dot(wi, wh);
-            float Fo = schlick_weight(AbsCosTheta(wo)), Fi = schlick_weight(AbsCosTheta(wi));
+            float Fo = wc.Fo, Fi = schlick_weight(AbsCosTheta(wi));
             float Rr = 2 * m.roughness * cosThetaD * cosThetaD;
             e.f = mat_v3(m.diffuse_R) * AGPT_INVPI * Rr * (Fo + Fi + Fo * Fi * (Rr - 1));
         }
@@ -216,7 +223,7 @@ __device__ __forceinline__ LobeEval lobe_eval(const DevMaterial& m, int lobe, v3
         if (f_ok || pdf_ok) {
             v3 wh = normalize(whs);
             float D = tr_D(m, wh);
-            float G1o = tr_G1(m, wo);
+            float G1o = wc.G1o;
             if (f_ok) {
                 v3 F = disney_fresnel(m, dot(wi, faceforward(wh, V3(0, 0, 1))));
                 float G = G1o * tr_G1(m, wi);  // DisneyMicrofacetDistribution::G disney.h:78-81
@@ -234,7 +241,7 @@ __device__ __forceinline__ LobeEval lobe_eval(const DevMaterial& m, int lobe, v3
 // pdf sum (the sampled lobe contributes the pdf its own Sample_f returned), pdf_init is the running value.
 // One shared, non-inlined copy: keeps k_shade inside the instruction cache.
 __device__ __noinline__ LobeEval bsdf_eval_lobes(const DevMaterial* mp, uint32_t mask, v3 wo, v3 wi, int skip_pdf_lobe,
-                                                 float pdf_init, bool want_f) {
+                                                 float pdf_init, bool want_f, WoCache wc) {
     const DevMaterial& m = *mp;
     LobeEval acc;
     acc.f = V3s(0.f);
@@ -242,7 +249,7 @@ __device__ __noinline__ LobeEval bsdf_eval_lobes(const DevMaterial* mp, uint32_t
 #pragma unroll 1
     for (int lobe = 0; lobe < 4; ++lobe) {
         if (!(mask & LOBE_BIT(lobe))) continue;
-        LobeEval e = lobe_eval(m, lobe, wo, wi);
+        LobeEval e = lobe_eval(m, lobe, wo, wi, wc);
         if (want_f) acc.f = acc.f + e.f;
         if (lobe != skip_pdf_lobe) acc.pdf += e.pdf;
     }
@@ -270,12 +277,19 @@ __device__ __forceinline__ v3 l2w(const Bsdf& b, v3 v) {
     return V3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
               b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
 }
+__device__ __forceinline__ WoCache bsdf_wo_cache(const Bsdf& b, const DevMaterial& m, v3 woW) {
+    const v3 wo = w2l(b, woW);
+    WoCache wc;
+    wc.G1o = (b.lobes & LOBE_BIT(LOBE_MICROFACET)) ? tr_G1(m, wo) : 0.f;
+    wc.Fo = schlick_weight(AbsCosTheta(wo));
+    return wc;
+}
 __device__ __forceinline__ bool bsdf_is_perfectly_specular(const Bsdf& b) {
     return (b.lobes & ~LOBE_BIT(LOBE_SPECULAR)) == 0;  // vacuously true for an empty list, like the reference's loop
 }
 // BSDF::f and BSDF::Pdf for one (wo, wi) pair (reflection.h:114-123, 174-188)
-__device__ __forceinline__ void bsdf_f_pdf(const Bsdf& b, const DevMaterial& m, v3 woW, v3 wiW, bool skipSpecular, v3* f_out,
-                                           float* pdf_out) {
+__device__ __forceinline__ void bsdf_f_pdf(const Bsdf& b, const DevMaterial& m, const WoCache& wc, v3 woW, v3 wiW,
+                                           bool skipSpecular, v3* f_out, float* pdf_out) {
     *f_out = V3s(0.f);
     *pdf_out = 0.f;
     if (b.lobes == 0) return;
@@ -284,25 +298,14 @@ __device__ __forceinline__ void bsdf_f_pdf(const Bsdf& b, const DevMaterial& m, 
     bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
     uint32_t mask = lobes_matching(b, skipSpecular);
     int matching = __popc(mask);
-    LobeEval e = bsdf_eval_lobes(&m, mask, wo, wi, -1, 0.f, reflect);
+    LobeEval e = bsdf_eval_lobes(&m, mask, wo, wi, -1, 0.f, reflect, wc);
     if (reflect) *f_out = e.f;
     *pdf_out = matching > 0 ? e.pdf / matching : 0.f;
 }
-__device__ __forceinline__ v3 bsdf_f(const Bsdf& b, const DevMaterial& m, v3 woW, v3 wiW, bool skipSpecular) {
-    v3 f;
-    float pdf;
-    bsdf_f_pdf(b, m, woW, wiW, skipSpecular, &f, &pdf);
-    return f;
-}
-__device__ __forceinline__ float bsdf_pdf(const Bsdf& b, const DevMaterial& m, v3 woW, v3 wiW, bool skipSpecular) {
-    v3 f;
-    float pdf;
-    bsdf_f_pdf(b, m, woW, wiW, skipSpecular, &f, &pdf);
-    return pdf;
-}
 // the chosen lobe's own Sample_f: returns its f (only used for the specular lobe); *pdf is written only on the paths
 // the reference writes it (quirk 8)
-__device__ __forceinline__ v3 lobe_sample(const DevMaterial& m, int lobe, v3 wo, v3* wi, float u0, float u1, float* pdf) {
+__device__ __forceinline__ v3 lobe_sample(const DevMaterial& m, int lobe, v3 wo, v3* wi, float u0, float u1, float* pdf,
+                                          const WoCache& wc) {
     if (lobe == LOBE_DIFFUSE || lobe == LOBE_RETRO) {  // BxDF::Sample_f reflection.h:8-15
         *wi = cosine_sample_hemisphere(u0, u1);
         if (wo.z < 0) wi->z *= -1;
@@ -317,7 +320,7 @@ __device__ __forceinline__ v3 lobe_sample(const DevMaterial& m, int lobe, v3 wo,
         if (dot(wo, wh) < 0) return V3s(0.f);
         *wi = reflect3(wo, wh);
         if (!same_hemisphere(wo, *wi)) return V3s(0.f);
-        *pdf = tr_pdf(m, wo, wh) / (4 * dot(wo, wh));
+        *pdf = tr_pdf(m, wo, wh, wc.G1o) / (4 * dot(wo, wh));
         return V3s(1.f);
     }
     // SpecularReflection::Sample_f reflection.cpp:13-18, FresnelNoOp
@@ -326,8 +329,8 @@ __device__ __forceinline__ v3 lobe_sample(const DevMaterial& m, int lobe, v3 wo,
     return V3s(1.f) * mat_v3(m.mirror_R) / AbsCosTheta(*wi);
 }
 // BSDF::Sample_f reflection.h:124-172.  pdf_io: the caller's variable (left untouched on the wo.z==0 early out, quirk 9)
-__device__ __forceinline__ v3 bsdf_sample_f(const Bsdf& b, const DevMaterial& m, v3 woW, v3* wiW, float u0, float u1,
-                                            float* pdf_io, bool skipSpecular, bool* sampledSpecular) {
+__device__ __forceinline__ v3 bsdf_sample_f(const Bsdf& b, const DevMaterial& m, const WoCache& wc, v3 woW, v3* wiW, float u0,
+                                            float u1, float* pdf_io, bool skipSpecular, bool* sampledSpecular) {
     uint32_t mask = lobes_matching(b, skipSpecular);
     int matching = __popc(mask);
     if (matching == 0) {
@@ -345,7 +348,7 @@ __device__ __forceinline__ v3 bsdf_sample_f(const Bsdf& b, const DevMaterial& m,
     if (wo.z == 0) return V3s(0.f);
     *pdf_io = 0;
     if (sampledSpecular) *sampledSpecular = (lobe == LOBE_SPECULAR);
-    v3 f = lobe_sample(m, lobe, wo, &wi, ur0, u1, pdf_io);
+    v3 f = lobe_sample(m, lobe, wo, &wi, ur0, u1, pdf_io, wc);
     if (*pdf_io == 0) return V3s(0.f);
     *wiW = l2w(b, wi);
     if (lobe == LOBE_SPECULAR) {
@@ -354,7 +357,7 @@ __device__ __forceinline__ v3 bsdf_sample_f(const Bsdf& b, const DevMaterial& m,
     }
     bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
     // *pdf += other lobes' Pdf (in list order), f = sum of all matching lobes' f if reflect
-    LobeEval e = bsdf_eval_lobes(&m, mask, wo, wi, matching > 1 ? lobe : -2, *pdf_io, reflect);
+    LobeEval e = bsdf_eval_lobes(&m, mask, wo, wi, matching > 1 ? lobe : -2, *pdf_io, reflect, wc);
     if (matching > 1) *pdf_io = e.pdf / matching;
     return reflect ? e.f : V3s(0.f);
 }
