@@ -32,7 +32,9 @@
 #define AGPT_HIT_SPHERE 0x80000000u   // analytic primitive (sphere or plane): low bits = primitive index
 
 #define AGPT_TRI_FLAG_REJECT 1u     // degenerate triangle: TriangleIntersect returns false after the t test
+#ifndef AGPT_STACK_DEPTH
 #define AGPT_STACK_DEPTH 32         // per-lane traversal stack entries staged in LDS (production kernel)
+#endif
 #define AGPT_STACK_DEPTH_MAX 64     // deepest BVH the generic kernel's 64-entry variant can walk
 
 // traversal-stack / node encoding: bit31 = leaf.  leaf with count<=7: bits 28..30 = count-1, bits 0..27 = first slot.
