@@ -200,3 +200,41 @@ def test_degenerate_scenes_and_calls():
         ag.PathTracer(5).render(g, 48, 48, 1, ptr, tile=(40, 40, 16, 16))   # tile outside the film
     ctx.free(ptr)
     g.close()
+
+
+def stacked_triangles(n, centre, seed):
+    """n triangles whose bounding boxes share one centre exactly: the builder cannot split them (degenerate centroid
+    bounds, bvhtrimesh.h:236-247) and emits ONE leaf of n primitives whatever maxPrimsInNode says."""
+    rng = np.random.RandomState(seed)
+    c = np.float32(centre)
+    v = []
+    for i in range(n):
+        a, b, h = (rng.randint(1, 16, 3) / np.float32(8.0)).astype(np.float32)
+        v += [c + np.float32([-a, -b, -h]), c + np.float32([a, -b, h]), c + np.float32([rng.choice([-a, a]), b, 0])]
+    v = np.array(v, np.float32)
+    return v, np.stack([np.arange(3 * n, dtype=np.int32)] * 3, 1)
+
+
+def test_multi_triangle_leaves_inline_and_big():
+    """Leaves of 5 (inline count encoding), 20 (big-leaf side table) and a mesh whose ROOT is one 12-triangle leaf."""
+    hv, hn, ht, hidx = ag.scenes.heightfield(15)
+    v5, i5 = stacked_triangles(5, [4, 1, 0], 1)
+    v20, i20 = stacked_triangles(20, [-4, 1, 1], 2)
+    v = np.concatenate([hv, v5, v20])
+    idx = np.concatenate([hidx, i5 + len(hv), i20 + len(hv) + len(v5)])
+    idx[:, 1:] = 0
+    nodes, order, depth = ag.bvh_build(v, idx, 1)
+    counts = sorted(set(int(c) for c in nodes["count"]))
+    assert 5 in counts and 20 in counts
+    d = ag.SceneDesc("leaves")
+    m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
+    d.add_mesh(v, None, None, idx, m, 1)
+    v12, i12 = stacked_triangles(12, [0, 3, 0], 3)
+    d.add_mesh(v12, None, None, i12, m, 1)
+    nodes12, _, _ = ag.bvh_build(v12, i12, 1)
+    assert int(nodes12["count"][0]) == 12
+    rays = random_rays(d, 40000, seed=9)
+    # aim a third of the rays at the stacks so that the multi-triangle leaves are really entered
+    tgt = np.float32([[4, 1, 0], [-4, 1, 1], [0, 3, 0]])[np.arange(len(rays) // 3) % 3]
+    rays["d"][:len(tgt)] = tgt + np.random.RandomState(4).normal(0, 0.4, tgt.shape).astype(np.float32) - rays["o"][:len(tgt)]
+    assert check_closest(d, rays) > 8000
