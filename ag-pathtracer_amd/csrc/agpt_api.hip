@@ -595,12 +595,15 @@ int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* o
     int blocks = (n + AGPT_BLOCK - 1) / AGPT_BLOCK;
     hipLaunchKernelGGL(k_prepare_rays, dim3(blocks), dim3(AGPT_BLOCK), 0, c->stream, d_rays, n, c->ext_o.p, c->ext_d.p);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    // stats requested -> the instrumented reference-order kernel (work counters); AGPT_INTERSECT_TIMING=1 (developer knob)
+    // keeps the production kernel so that stats->trace_ms times it
+    const bool instrumented = stats != nullptr && !getenv("AGPT_INTERSECT_TIMING");
     if (any_hit)
         launch_trace<1>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
-                           stats != nullptr);
+                           instrumented);
     else
         launch_trace<0>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
-                            stats != nullptr);
+                            instrumented);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     hipLaunchKernelGGL(k_export_hits, dim3(blocks), dim3(AGPT_BLOCK), 0, c->stream, s->dev, c->hit.p, c->occluded.p, n, any_hit,
                        d_out);
