@@ -119,7 +119,7 @@ static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
 static int trace_grid(const agpt_ctx* c) { return c->num_cus * c->blocks_per_cu; }
 
 static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, bool count) {
-    return !count && sc.n_prims <= 64 && sc.max_depth <= AGPT_STACK_DEPTH && !c->force_generic;
+    return !count && sc.n_prims <= 64 && !c->force_generic;
 }
 
 // MODE 0 closest, 1 any-hit, 2 MIS query (production kernel only; the generic kernel traces MIS rays as closest hits)
@@ -128,10 +128,15 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
                          uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, bool count) {
     constexpr bool ANY = MODE == 1;
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
-    if (use_fast_trace(c, sc, count))
-        hipLaunchKernelGGL((k_trace_fast<MODE>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm, work_head, ro, rd,
-                           hits, occ, c->counters.p, MODE == 0 ? c->refill : c->refill_any);
-    else if (sc.max_depth > AGPT_STACK_DEPTH) {
+    if (use_fast_trace(c, sc, count)) {
+        if (sc.max_depth <= AGPT_STACK_DEPTH)
+            hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm,
+                               work_head, ro, rd, hits, occ, c->counters.p, MODE == 0 ? c->refill : c->refill_any);
+        else  // deep BVH: 64-entry stacks, half the blocks per CU
+            hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH_MAX>), dim3(c->num_cus * 2), block, 0, c->stream, sc, queue,
+                               count_ptr, count_imm, work_head, ro, rd, hits, occ, c->counters.p,
+                               MODE == 0 ? c->refill : c->refill_any);
+    } else if (sc.max_depth > AGPT_STACK_DEPTH) {
         dim3 grid_deep(c->num_cus * 2);
         if (count)
             hipLaunchKernelGGL((k_trace<ANY, true, AGPT_STACK_DEPTH_MAX>), grid_deep, block, 0, c->stream, sc, queue, count_ptr,

@@ -184,14 +184,16 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 //     root_P < t_s when P precedes S in Scene::primitives and root_P <= t_s when it follows (Sphere::Intersect accepts
 //     root <= ray.t, so a tie goes to the later primitive); degenerate triangles never block (quirk 11).
 // Every MIS ray is still traced through the BVH; it stops at the first blocker instead of finishing a closest-hit search.
-template <int MODE>
+// DEPTH: per-lane stack entries in LDS -- AGPT_STACK_DEPTH (32 KiB/block, 4 blocks per CU) for the usual trees,
+// AGPT_STACK_DEPTH_MAX (64 KiB/block, 2 blocks per CU) for BVHs deeper than that
+template <int MODE, int DEPTH>
 __global__ void __launch_bounds__(AGPT_BLOCK)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
              DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters, int refill) {
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
-    __shared__ uint32_t s_stack[AGPT_STACK_DEPTH * AGPT_BLOCK];
+    __shared__ uint32_t s_stack[DEPTH * AGPT_BLOCK];
     __shared__ float4 s_prim[2 * 64];
     uint32_t* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
