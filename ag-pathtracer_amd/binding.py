@@ -27,7 +27,7 @@ EXPORTS = [
     "agpt_scene_add_plane", "agpt_scene_add_area_light", "agpt_scene_add_uniform_infinite_light", "agpt_scene_add_infinite_area_light",
     "agpt_scene_set_camera",
     "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_create_backdrop",
-    "agpt_intersect_batch", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
+    "agpt_intersect_batch", "agpt_intersect_device", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
     "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
     "agpt_obj_free", "agpt_obj_last_error", "agpt_write_png", "agpt_write_pfm",
@@ -114,6 +114,7 @@ def lib():
     L.agpt_bvh_build.argtypes = [fp, C.c_int, ip, C.c_int, C.c_int, vp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.agpt_create_backdrop.argtypes = [fp, fp, C.c_float, C.c_int, fp, fp, fp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.agpt_intersect_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Stats)]
+    L.agpt_intersect_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.agpt_render.argtypes = [vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]
     L.agpt_resolve.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     L.agpt_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -378,6 +379,13 @@ class Scene:
                                            C.byref(st) if counters else None),
                "agpt_intersect_batch")
         return out, st
+
+    def intersect_device(self, rays_ptr, n, out_ptr, any_hit=False, counters=False):
+        """agpt_intersect_device: rays / hits stay in HBM (pointers from Context.alloc or the host's own allocations)."""
+        st = Stats()
+        _check(self.L.agpt_intersect_device(self.h, C.c_void_p(rays_ptr), int(n), C.c_void_p(out_ptr), int(any_hit),
+                                            C.byref(st) if counters else None), "agpt_intersect_device")
+        return st
 
     def Intersect(self, rays, counters=False):
         """Scene::Intersect for a batch of rays (scene.h:5-13).  counters=True runs the instrumented kernel

@@ -582,19 +582,14 @@ static void read_counters(const DevCounters& d, agpt_stats* st) {
     st->samples = d.samples;
 }
 
-int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* out, int any_hit, agpt_stats* stats) {
-    if (!s || !rays || !out || n < 0) return fail(AGPT_ERR_INVALID, "agpt_intersect_batch: bad argument");
-    if (!s->committed) return fail(AGPT_ERR_INVALID, "agpt_intersect_batch: scene not committed");
+int agpt_intersect_device(agpt_scene* s, const agpt_ray* d_rays, int n, agpt_hit* d_out, int any_hit, agpt_stats* stats) {
+    if (!s || !d_rays || !d_out || n < 0) return fail(AGPT_ERR_INVALID, "agpt_intersect_device: bad argument");
+    if (!s->committed) return fail(AGPT_ERR_INVALID, "agpt_intersect_device: scene not committed");
     if (n == 0) return AGPT_OK;
     agpt_ctx* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_pool(c, (size_t)n);
     if (rc) return rc;
-    agpt_ray* d_rays = nullptr;
-    agpt_hit* d_out = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * sizeof(agpt_ray)));
-    HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * sizeof(agpt_hit)));
-    HIP_TRY(hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(agpt_ray), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipMemsetAsync(c->work.p, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
     int blocks = (n + AGPT_BLOCK - 1) / AGPT_BLOCK;
@@ -605,14 +600,13 @@ int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* o
     const bool instrumented = stats != nullptr && !getenv("AGPT_INTERSECT_TIMING");
     if (any_hit)
         launch_trace<1>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
-                           instrumented);
+                        instrumented);
     else
         launch_trace<0>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
-                            instrumented);
+                        instrumented);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     hipLaunchKernelGGL(k_export_hits, dim3(blocks), dim3(AGPT_BLOCK), 0, c->stream, s->dev, c->hit.p, c->occluded.p, n, any_hit,
                        d_out);
-    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(agpt_hit), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     if (stats) {
@@ -626,9 +620,31 @@ int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* o
         stats->total_ms = ms;
         stats->trace_launches = 1;
     }
-    HIP_TRY(hipFree(d_rays));
-    HIP_TRY(hipFree(d_out));
     return AGPT_OK;
+}
+
+int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* out, int any_hit, agpt_stats* stats) {
+    if (!s || !rays || !out || n < 0) return fail(AGPT_ERR_INVALID, "agpt_intersect_batch: bad argument");
+    if (!s->committed) return fail(AGPT_ERR_INVALID, "agpt_intersect_batch: scene not committed");
+    if (n == 0) return AGPT_OK;
+    agpt_ctx* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    agpt_ray* d_rays = nullptr;
+    agpt_hit* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * sizeof(agpt_ray)));
+    if (hipMalloc((void**)&d_out, (size_t)n * sizeof(agpt_hit)) != hipSuccess) {
+        (void)hipFree(d_rays);
+        return fail(AGPT_ERR_NOMEM, "agpt_intersect_batch: out of device memory");
+    }
+    int rc = AGPT_OK;
+    if (hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(agpt_ray), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = fail(AGPT_ERR_DEVICE, "agpt_intersect_batch: upload failed");
+    if (rc == AGPT_OK) rc = agpt_intersect_device(s, d_rays, n, d_out, any_hit, stats);
+    if (rc == AGPT_OK && hipMemcpy(out, d_out, (size_t)n * sizeof(agpt_hit), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(AGPT_ERR_DEVICE, "agpt_intersect_batch: download failed");
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    return rc;
 }
 
 int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, agpt_stats* stats) {

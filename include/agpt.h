@@ -176,6 +176,9 @@ const char* agpt_obj_last_error(void);
  * rays/out are HOST arrays (copied in/out); BVHTriMesh::RecursiveHit/RecursiveHitP (bvhtrimesh.h:332-413),
  * TriangleIntersect/P (trianglemesh.cpp:7-155), Sphere::Intersect/P (intersectable.h:164-226) run on the GPU. */
 int agpt_intersect_batch(agpt_scene*, const agpt_ray* rays, int n, agpt_hit* out, int any_hit, agpt_stats* stats);
+/* Same, with rays_dev / out_dev DEVICE arrays (e.g. from agpt_device_alloc or the host application's own HIP
+ * allocations): nothing crosses PCIe; enqueued on the context's stream and synchronised before returning. */
+int agpt_intersect_device(agpt_scene*, const agpt_ray* rays_dev, int n, agpt_hit* out_dev, int any_hit, agpt_stats* stats);
 
 /* MyApp::Tick's loop body for every pixel of the tile and every sample in the range:
  *   jitter -> Camera::GetRay -> PathTracer::Li -> NaN/inf reject -> Accumulator::AddSample  (myapp.cpp:165-173)

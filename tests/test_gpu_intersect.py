@@ -238,3 +238,27 @@ def test_multi_triangle_leaves_inline_and_big():
     tgt = np.float32([[4, 1, 0], [-4, 1, 1], [0, 3, 0]])[np.arange(len(rays) // 3) % 3]
     rays["d"][:len(tgt)] = tgt + np.random.RandomState(4).normal(0, 0.4, tgt.shape).astype(np.float32) - rays["o"][:len(tgt)]
     assert check_closest(d, rays) > 8000
+
+
+def test_device_pointer_entry_point_matches_host_entry_point():
+    """agpt_intersect_device (rays and hits resident in HBM) == agpt_intersect_batch (host arrays), closest and any-hit."""
+    d = ag.scenes.scene_c1()
+    rays = random_rays(d, 50000, seed=11)
+    g = gpu_scene(d)
+    ctx = g.ctx
+    host_hits, _ = g.Intersect(rays)
+    host_occ, _ = g.IntersectP(rays)
+    rp = ctx.alloc(rays.nbytes)
+    hp = ctx.alloc(len(rays) * ag.HIT_DTYPE.itemsize)
+    ctx.upload(rp, rays)
+    g.intersect_device(rp, len(rays), hp)
+    dev_hits = ctx.download(hp, (len(rays),), ag.HIT_DTYPE)
+    assert dev_hits.tobytes() == host_hits.tobytes()
+    st = g.intersect_device(rp, len(rays), hp, any_hit=True, counters=True)
+    dev_occ = ctx.download(hp, (len(rays),), ag.HIT_DTYPE)
+    assert np.array_equal(dev_occ["hit"], host_occ["hit"]) and st.anyhit_rays == len(rays)
+    with pytest.raises(ag.AgptError):
+        g.intersect_device(0, 4, hp)
+    ctx.free(rp)
+    ctx.free(hp)
+    g.close()
