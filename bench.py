@@ -248,6 +248,10 @@ def main():
                 "trace_split_ms_per_step": {"continuation": round(sums["ext_ms"] / args.steps, 2), "mis": round(sums["mis_ms"] / args.steps, 2),
                                             "shadow": round(sums["shadow_ms"] / args.steps, 2)},
                 "trace_only_mrays_s": round(rays_rank0 / trace_s / 1e6, 1) if trace_s > 0 else None,
+                # measured HBM rate of the same kernel: PMC traffic per launch (profiles/traffic.json) / live launch time
+                "traffic_gbs": round(traffic / (sums["trace_ms"] / launches * 1e-3) / 1e9, 1) if traffic and trace_s > 0 else None,
+                "traffic_frac_of_peak": round(traffic / (sums["trace_ms"] / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                if traffic and trace_s > 0 else None,
             },
             "image_mean_rgb": [round(x, 6) for x in img_mean] if img_mean else None,
         }
