@@ -362,7 +362,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         mis_skip = -1;
                         mis_reach = true;
                         const DevLight& lt = sc.lights[__float_as_uint(d.w)];
-#ifndef AGPT_EXP_NOSPHERE
                         if (lt.type == AGPT_LIGHT_AREA) {
                             const float4 sa = s_prim[2 * lt.shape], sb = s_prim[2 * lt.shape + 1];
                             float ts;
@@ -370,9 +369,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                             mis_reach = sphere_test_c(V3(sa.x, sa.y, sa.z), sb.x, r, rayt, ts);
                             if (mis_reach) rayt = ts;
                         }
-#else
-                        mis_skip = lt.shape;
-#endif
                     }
                     hid = AGPT_HIT_MISS;
                     hb1 = 0.f;
