@@ -119,7 +119,7 @@ static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
 static int trace_grid(const agpt_ctx* c) { return c->num_cus * c->blocks_per_cu; }
 
 static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, bool count) {
-    return !count && sc.n_prims <= 64 && !c->force_generic;
+    return !count && sc.n_prims <= 64 * AGPT_MAX_CHUNKS && !c->force_generic;
 }
 
 // MODE 0 closest, 1 any-hit, 2 MIS query (production kernel only; the generic kernel traces MIS rays as closest hits)
@@ -129,13 +129,29 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     constexpr bool ANY = MODE == 1;
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
     if (use_fast_trace(c, sc, count)) {
-        if (sc.max_depth <= AGPT_STACK_DEPTH)
-            hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH>), grid, block, 0, c->stream, sc, queue, count_ptr, count_imm,
-                               work_head, ro, rd, hits, occ, c->counters.p, MODE == 0 ? c->refill : c->refill_any);
-        else  // deep BVH: 64-entry stacks, half the blocks per CU
-            hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH_MAX>), dim3(c->num_cus * 2), block, 0, c->stream, sc, queue,
-                               count_ptr, count_imm, work_head, ro, rd, hits, occ, c->counters.p,
-                               MODE == 0 ? c->refill : c->refill_any);
+        const int refill = MODE == 0 ? c->refill : c->refill_any;
+        const bool deep = sc.max_depth > AGPT_STACK_DEPTH;   // deep BVH: 64-entry stacks, half the blocks per CU
+        const dim3 g = deep ? dim3(c->num_cus * 2) : grid;
+        if (sc.n_prims <= 64) {
+            if (!deep)
+                hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH, false>), g, block, 0, c->stream, sc, queue, count_ptr,
+                                   count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0);
+            else
+                hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH_MAX, false>), g, block, 0, c->stream, sc, queue, count_ptr,
+                                   count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0);
+        } else {
+            // more than 64 primitives: one launch per list-order chunk of 64 over the same queue
+            const int chunks = (sc.n_prims + 63) / 64;
+            for (int ch = 0; ch < chunks; ch++) {
+                if (ch > 0) (void)hipMemsetAsync(work_head, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream);
+                if (!deep)
+                    hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH, true>), g, block, 0, c->stream, sc, queue, count_ptr,
+                                       count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, ch);
+                else
+                    hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH_MAX, true>), g, block, 0, c->stream, sc, queue,
+                                       count_ptr, count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, ch);
+            }
+        }
     } else if (sc.max_depth > AGPT_STACK_DEPTH) {
         dim3 grid_deep(c->num_cus * 2);
         if (count)
@@ -453,7 +469,7 @@ int agpt_scene_commit(agpt_scene* s) {
     s->dev.n_infinite = n_inf;
     s->dev.max_depth = flat.max_depth;
     s->dev.rootpair_base = flat.rootpair_base;
-    s->dev.mesh_mask = flat.mesh_mask;
+    for (int ch = 0; ch < AGPT_MAX_CHUNKS; ch++) s->dev.mesh_masks[ch] = flat.mesh_masks[ch];
     s->dev.n_meshes = 0;
     for (const DevPrim& dp : flat.prims)
         if (dp.type == AGPT_PRIM_MESH && dp.n_tris > 0) s->dev.n_meshes++;

@@ -383,8 +383,9 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
         tri_base += meshes[m].prim_index.size();
     }
     out.rootpair_base = (uint32_t)node_base;
-    out.mesh_mask = 0;
-    out.nodes.assign(2 * (node_base + 128), F4(0, 0, 0, 0));   // + 64 root-pair records (agpt_scene.h)
+    for (int c = 0; c < AGPT_MAX_CHUNKS; c++) out.mesh_masks[c] = 0;
+    const size_t n_rootpairs = std::min<size_t>(prims.size(), 64 * AGPT_MAX_CHUNKS);
+    out.nodes.assign(2 * (node_base + 2 * n_rootpairs), F4(0, 0, 0, 0));   // + the root-pair records (agpt_scene.h)
     out.tri_verts.resize(3 * tri_base);
     out.tri_shade.resize(4 * tri_base);
 
@@ -460,14 +461,14 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
                 out.bigleaves.push_back((uint32_t)r.count);
             }
         }
-        if (pi < 64 && n_tris > 0) {
+        if (pi < 64 * AGPT_MAX_CHUNKS && n_tris > 0) {
             float* rec = reinterpret_cast<float*>(&out.nodes[4 * ((out.rootpair_base + 2 * pi) >> 1)]);
             for (int a = 0; a < 3; a++) {
                 rec[2 * a] = rec[2 * a + 1] = dp.root_bmin[a];
                 rec[6 + 2 * a] = rec[6 + 2 * a + 1] = dp.root_bmax[a];
             }
             rec[12] = rec[13] = bits(dp.root_enc);
-            out.mesh_mask |= 1ull << pi;
+            out.mesh_masks[pi / 64] |= 1ull << (pi % 64);
         }
         // triangles
         const bool has_uv = !mesh.texcoords.empty();

@@ -68,7 +68,7 @@ struct FlatScene {
     std::vector<uint32_t> bigleaves;  // (first slot, count) pairs of leaves too big for the inline encoding
     int max_depth = 0;
     uint32_t rootpair_base = 0;        // node index of primitive 0's root pair (agpt_scene.h)
-    unsigned long long mesh_mask = 0;  // non-empty meshes among the first 64 primitives
+    unsigned long long mesh_masks[AGPT_MAX_CHUNKS] = {};  // non-empty meshes, one word per chunk of 64 primitives
 };
 // per-mesh concatenation + per-triangle precomputation (trianglemesh.cpp:46-111's ray-independent part)
 void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSphere>& spheres,

@@ -186,22 +186,29 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 // Every MIS ray is still traced through the BVH; it stops at the first blocker instead of finishing a closest-hit search.
 // DEPTH: per-lane stack entries in LDS -- AGPT_STACK_DEPTH (32 KiB/block, 4 blocks per CU) for the usual trees,
 // AGPT_STACK_DEPTH_MAX (64 KiB/block, 2 blocks per CU) for BVHs deeper than that
-template <int MODE, int DEPTH>
+// CHUNKED: scenes with more than 64 primitives are walked in list-order chunks of 64, one launch per chunk over the same
+// queue (the candidate mask is one 64-bit word).  chunk > 0 continues where the previous launch stopped: a closest-hit
+// ray starts from its hit record so far, an any-hit / MIS ray that is already decided is skipped, and only a blocker is
+// written -- exactly Scene::Intersect's sequential walk with a shared ray.t (scene.h:5-19).
+template <int MODE, int DEPTH, bool CHUNKED>
 __global__ void __launch_bounds__(AGPT_BLOCK)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-             DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters, int refill) {
+             DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters, int refill,
+             int chunk) {
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
+    const int prim_base = CHUNKED ? 64 * chunk : 0;
+    const bool carry = CHUNKED && chunk > 0;
     __shared__ uint32_t s_stack[DEPTH * AGPT_BLOCK];
     __shared__ float4 s_prim[2 * 64];
     uint32_t* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t count = count_ptr ? *count_ptr : count_imm;
-    const int n_prims = sc.n_prims;
+    const int n_prims = CHUNKED ? (sc.n_prims - prim_base < 64 ? sc.n_prims - prim_base : 64) : sc.n_prims;
     if ((int)threadIdx.x < n_prims) {
-        const DevPrim& P = sc.prims[threadIdx.x];
+        const DevPrim& P = sc.prims[prim_base + threadIdx.x];
         float4 a, b;
         if (P.type == AGPT_PRIM_SPHERE) {
             a.x = P.cx; a.y = P.cy; a.z = P.cz; a.w = 1.f;
@@ -229,8 +236,21 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     // anything below = an interior child-pair index (state B), sign bit set = a leaf encoding (state C).  One v_cmp per
     // state gives the wave's vote masks.
     constexpr uint32_t CUR_IDLE = 0x7FFFFFFFu, CUR_PICK = 0x7FFFFFFEu;
-    const uint32_t rootpair_base = sc.rootpair_base;
-    const unsigned long long mesh_mask = sc.mesh_mask;
+    const uint32_t rootpair_base = sc.rootpair_base + 2u * (uint32_t)prim_base;
+    const unsigned long long mesh_mask = CHUNKED ? sc.mesh_masks[chunk] : sc.mesh_masks[0];
+    // the sphere of an area light as (centre, r2), wherever it sits in the primitive list
+    auto light_sphere = [&](int shape, v3& c, float& r2) {
+        const int ls = shape - prim_base;
+        if (!CHUNKED || (ls >= 0 && ls < n_prims)) {
+            const float4 sa = s_prim[2 * ls], sb = s_prim[2 * ls + 1];
+            c = V3(sa.x, sa.y, sa.z);
+            r2 = sb.x;
+        } else {
+            const DevPrim& P = sc.prims[shape];
+            c = V3(P.cx, P.cy, P.cz);
+            r2 = P.r2;
+        }
+    };
     // Scene::Intersect's walk to the next primitive of the list (scene.h:8-17).  A mesh is entered through its root
     // pair -- the root-box test becomes the lane's next interior step (state B); spheres, planes and the end of the
     // list go through state A.
@@ -261,6 +281,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     uint32_t* ring_pid = s_ring_pid[threadIdx.x >> 6];
     unsigned long long* ring_mask = s_ring_mask[threadIdx.x >> 6];
     uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, monotonically increasing
+    bool mis_area = false;    // MODE 2: the sampled light is an area light
     int mis_skip = -1;        // MODE 2: primitive index of the sampled area light's sphere (never a blocker itself)
     bool mis_reach = true;    // MODE 2: infinite light, or the ray reaches the light's sphere
     bool any_slow = false;                  // wave-uniform: some active lane's ray needs the true-division slab test
@@ -304,13 +325,22 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     const float4 d = ray_d[npid];
                     const TraceRay nr = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                     unsigned long long skip_bit = 0;
+                    bool decided = false;  // chunk > 0: nothing in this chunk can change the ray's answer any more
+                    if (carry) {
+                        if (MODE == 0)
+                            o.w = hits[npid].t;
+                        else
+                            decided = MODE == 1 ? occluded[npid] != 0u : occluded[npid] == 0u;
+                    }
                     if (MIS) {
                         const DevLight& lt = sc.lights[__float_as_uint(d.w)];
                         if (lt.type == AGPT_LIGHT_AREA) {
-                            const float4 sa = s_prim[2 * lt.shape], sb = s_prim[2 * lt.shape + 1];
-                            float ts;
-                            if (sphere_test_c(V3(sa.x, sa.y, sa.z), sb.x, nr, o.w, ts)) o.w = ts;
-                            skip_bit = 1ull << lt.shape;
+                            v3 lc;
+                            float lr2, ts;
+                            light_sphere(lt.shape, lc, lr2);
+                            if (sphere_test_c(lc, lr2, nr, o.w, ts)) o.w = ts;
+                            const int ls = lt.shape - prim_base;
+                            if (!CHUNKED || (ls >= 0 && ls < 64)) skip_bit = 1ull << ls;
                         }
                     }
                     // phase A: conservative per-primitive filter at the initial t.  t ~ fma(b, R, -RN(O*R)) differs from
@@ -338,7 +368,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                     const uint32_t slot = (ring_tail + (uint32_t)lane) & (AGPT_RING - 1);
                     ring_pid[slot] = npid;
-                    ring_mask[slot] = (nr.fast ? m : all_prims) & ~skip_bit;
+                    ring_mask[slot] = decided ? 0ull : ((nr.fast ? m : all_prims) & ~skip_bit);
                 }
                 ring_tail += n_new;
                 TS(ts_pref++;)
@@ -359,20 +389,30 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     r = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                     rayt = o.w;
                     if (MIS) {
+                        mis_area = false;
                         mis_skip = -1;
                         mis_reach = true;
                         const DevLight& lt = sc.lights[__float_as_uint(d.w)];
                         if (lt.type == AGPT_LIGHT_AREA) {
-                            const float4 sa = s_prim[2 * lt.shape], sb = s_prim[2 * lt.shape + 1];
-                            float ts;
-                            mis_skip = lt.shape;
-                            mis_reach = sphere_test_c(V3(sa.x, sa.y, sa.z), sb.x, r, rayt, ts);
+                            v3 lc;
+                            float lr2, ts;
+                            light_sphere(lt.shape, lc, lr2);
+                            mis_area = true;
+                            mis_skip = lt.shape - prim_base;   // position in this chunk's numbering (may lie outside it)
+                            mis_reach = sphere_test_c(lc, lr2, r, rayt, ts);
                             if (mis_reach) rayt = ts;
                         }
                     }
                     hid = AGPT_HIT_MISS;
                     hb1 = 0.f;
                     hb2 = 0.f;
+                    if (MODE == 0 && carry) {
+                        const DevHit ph = hits[pid];
+                        rayt = ph.t;
+                        hid = ph.id;
+                        hb1 = ph.b1;
+                        hb2 = ph.b2;
+                    }
                     sp = 0;
                     cur = pick_next(mask);
                 }
@@ -463,11 +503,11 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             } else if (cur == CUR_PICK) {
                 // end of the primitive list (retire), or the sphere / plane that is next in list order
                 if (mask == 0) {
-                    if (MIS)
-                        occluded[pid] = mis_reach ? 1u : 0u;
-                    else if (ANY)
-                        occluded[pid] = 0u;
-                    else {
+                    if (MIS) {
+                        if (!carry) occluded[pid] = mis_reach ? 1u : 0u;   // later chunks only ever write a blocker
+                    } else if (ANY) {
+                        if (!carry) occluded[pid] = 0u;
+                    } else {
                         DevHit h;
                         h.t = rayt;
                         h.id = hid;
@@ -485,7 +525,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         if (analytic_test(pa.w, V3(pa.x, pa.y, pa.z), pb2.x, pb2.y, r, rayt, root)) {
                             if (MIS) {
                                 // a sphere listed before the light's sphere only wins a strict comparison (see above)
-                                const bool tie_loses = pa.w == 1.f && mis_skip >= 0 && mis_reach && k < mis_skip && root == rayt;
+                                const bool tie_loses = pa.w == 1.f && mis_area && mis_reach && k < mis_skip && root == rayt;
                                 if (!tie_loses) {
                                     occluded[pid] = 0u;
                                     cur = CUR_IDLE;
@@ -495,7 +535,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                                 cur = CUR_IDLE;
                             } else {
                                 rayt = root;
-                                hid = AGPT_HIT_SPHERE | (uint32_t)k;
+                                hid = AGPT_HIT_SPHERE | (uint32_t)(prim_base + k);
                                 hb1 = 0.f;
                                 hb2 = 0.f;
                             }
@@ -511,7 +551,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         for (int k = 0; k < 3; ++k) { atomicAdd(d + k, ts_steps[k]); atomicAdd(d + 3 + k, ts_lanes[k]); }
         atomicAdd(d + 6, ts_act); atomicAdd(d + 7, ts_refills); atomicAdd(d + 8, ts_refilled); atomicAdd(d + 9, ts_pref);
     })
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !carry) {
         if (MODE == 1)
             atomicAdd(&counters->anyhit_rays, (unsigned long long)count);
         else

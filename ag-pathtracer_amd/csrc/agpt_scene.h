@@ -35,6 +35,7 @@
 #ifndef AGPT_STACK_DEPTH
 #define AGPT_STACK_DEPTH 32         // per-lane traversal stack entries staged in LDS (production kernel)
 #endif
+#define AGPT_MAX_CHUNKS 8           // the production trace kernel walks up to 8 x 64 primitives (one launch per chunk)
 #define AGPT_STACK_DEPTH_MAX 64     // deepest BVH the generic kernel's 64-entry variant can walk
 
 // traversal-stack / node encoding: bit31 = leaf.  leaf with count<=7: bits 28..30 = count-1, bits 0..27 = first slot.
@@ -103,12 +104,13 @@ struct DevScene {
     int32_t n_infinite;        // number of IsInfinite() lights
     int32_t n_meshes;          // non-empty mesh primitives
     int32_t max_depth;         // deepest BVH of the scene (selects the traversal-stack size)
-    // Root pairs: for each of the first 64 primitives that is a non-empty mesh, nodes[] holds one extra pair record at
+    // Root pairs: for each of the first 64 * AGPT_MAX_CHUNKS primitives that is a non-empty mesh, nodes[] holds one extra pair record at
     // node index rootpair_base + 2k whose LEFT box is the mesh's root box and whose encoding is the mesh's root -- the
     // reference's root-box test at BVHTriMesh::Intersect (bvhtrimesh.h:187,195) then runs as an ordinary interior step
-    // of the traversal kernel (the right half of the record is ignored).  mesh_mask: bit k set for those primitives.
+    // of the traversal kernel (the right half of the record is ignored).  mesh_masks: bit k of word c set for primitive
+    // 64c + k if it is such a mesh.
     uint32_t rootpair_base;
-    unsigned long long mesh_mask;
+    unsigned long long mesh_masks[AGPT_MAX_CHUNKS];   // per chunk of 64 primitives
     DevCamera cam;
 };
 

@@ -95,9 +95,8 @@ def test_empty_and_invalid_inputs():
     g.close()
 
 
-def test_more_than_64_primitives_uses_generic_kernel():
-    """> 64 primitives: the 64-bit primitive mask of the production kernel does not apply and the generic kernel runs
-    (chunks of 64 in list order)."""
+def test_more_than_64_primitives_are_walked_in_chunks():
+    """> 64 primitives: the production kernel is launched once per list-order chunk of 64 (75 primitives = 2 chunks)."""
     rng = np.random.RandomState(5)
     d = ag.SceneDesc("many")
     m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
@@ -262,3 +261,28 @@ def test_device_pointer_entry_point_matches_host_entry_point():
     ctx.free(rp)
     ctx.free(hp)
     g.close()
+
+
+def test_render_with_200_primitives_lights_in_different_chunks():
+    """Four chunks of the primitive list with meshes, spheres, two area lights (one in the first chunk, one in the last) and a
+    sky: closest-hit carry-over, any-hit and MIS queries across chunk boundaries, against the oracle."""
+    from test_gpu_render import compare
+    rng = np.random.RandomState(8)
+    d = ag.SceneDesc("200-prims")
+    mats = [d.add_material(ag.MAT_DISNEY, rng.uniform(.2, .9, 3), float(rng.uniform(.1, 1)), float(rng.choice([0., 1.]))) for _ in range(6)]
+    d.add_area_light([0.0, 6.0, 0.0], 0.7, [60, 55, 50])
+    for i in range(197):
+        c = rng.uniform(-5, 5, 3) * np.array([1, 0.5, 1])
+        if i % 4 == 3:
+            d.add_sphere(c, float(rng.uniform(0.15, 0.5)), mats[i % 6])
+        else:
+            v, n, t, idx = ag.scenes.blob_mesh(6, 5, center=tuple(c), radius=float(rng.uniform(0.2, 0.6)), seed=i)
+            d.add_mesh(v, n if i % 2 else None, t, idx, mats[i % 6], 1)
+    d.add_plane([0, -3.0, 0], [8, 8], mats[0])
+    d.add_area_light([3.0, 5.0, -2.0], 0.5, [40, 45, 60])
+    d.add_uniform_infinite_light([.3, .35, .4])
+    d.set_camera([0, 2, -12], [0, 0, 0], [0, 1, 0], 1.5, 50.0, 0.0)
+    assert d.n_prims == 200
+    compare(d, 96, 64, 2)
+    rays = random_rays(d, 60000, seed=3)
+    assert check_closest(d, rays) > 10000
