@@ -51,6 +51,15 @@ def random_scene(seed):
         d.add_mesh(v, nn, t, idx, mats[rng.randint(len(mats))], int(rng.choice([1, 1, 2, 4])))
     for _ in range(rng.randint(0, 4) + (1 if n_mesh == 0 else 0)):
         d.add_sphere(rng.uniform(-2, 2, 3), float(rng.uniform(0.1, 1.2)), mats[rng.randint(len(mats))])
+    if rng.uniform() < 0.12:   # a long primitive list: the production kernel walks it in chunks of 64
+        for i in range(rng.randint(60, 150)):
+            c = rng.uniform(-3, 3, 3)
+            if rng.uniform() < 0.5:
+                d.add_sphere(c, float(rng.uniform(0.05, 0.3)), mats[rng.randint(len(mats))])
+            else:
+                k = rng.randint(1, 5)
+                v = (c + rng.normal(size=(k, 3, 3)) * 0.3).astype(np.float32).reshape(-1, 3)
+                d.add_mesh(v, None, None, np.stack([np.arange(3 * k, dtype=np.int32)] * 3, 1), mats[rng.randint(len(mats))], 1)
     if rng.uniform() < 0.4:
         d.add_plane([float(rng.uniform(-1, 1)), float(rng.uniform(-2.5, -1)), float(rng.uniform(-1, 1))],
                     [float(rng.uniform(1, 6)), float(rng.uniform(1, 6))], mats[rng.randint(len(mats))])
