@@ -81,3 +81,12 @@ def test_invalid_arguments_return_errors():
     assert b"agpt_bvh_build" in L.agpt_last_error()
     with pytest.raises(ag.AgptError):
         ag.bvh_build(np.zeros((3, 3), np.float32), np.array([[0, 0, 0], [1, 1, 1], [7, 7, 7]], np.int32))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/agpt.h is the drop-in boundary: it must compile as C99 (no C++ or torch types in the signatures)."""
+    import subprocess
+    src = tmp_path / "c99.c"
+    src.write_text('#include "agpt.h"\nint main(void) { agpt_ctx* c = 0; return agpt_init(0, &c); }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])
