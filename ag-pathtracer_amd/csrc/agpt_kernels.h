@@ -158,15 +158,16 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Production trace kernel (scenes with <= 64 primitives; the generic k_trace above stays as the instrumented /
-// fallback variant and both are checked against the oracle).  Same decisions as trace_scene(), restructured for
-// wave efficiency on 64-wide CDNA4 wavefronts:
-//   * persistent waves with IN-FLIGHT REFILL: when at least AGPT_REFILL lanes have retired their rays the wave
-//     pulls that many new rays off the queue (one atomic per refill) instead of idling until all 64 are done;
-//   * while-while traversal: every lane first descends interior nodes (the hot, convergent body), leaves are
-//     processed once all lanes have reached one, then lanes whose mesh is finished pick their next primitive;
-//   * the wave-uniform phase-A filter uses the cheap slab test (b-O)*RN(1/D) with a widened reject margin, which
-//     can only over-accept; the exact Bounds::Intersect is re-run per lane where the reference runs it.
+// Production trace kernel (the generic k_trace above stays as the instrumented variant and the fallback for more than
+// 512 primitives; both are checked against the oracle and against each other).  Same decisions as trace_scene(),
+// restructured for wave efficiency on 64-wide CDNA4 wavefronts:
+//   * persistent waves with IN-FLIGHT REFILL: when at least AGPT_REFILL lanes have retired their rays the wave hands
+//     them new rays from a wave-private LDS ring instead of idling until all 64 are done;
+//   * PREFILTER RING: rays enter the ring 64 at a time (one atomic on the frontier counter of the wave's queue segment)
+//     with a per-primitive candidate mask from a cheap conservative slab test, all 64 lanes busy; the exact
+//     Bounds::Intersect is re-run per lane where the reference runs it;
+//   * VOTE-SCHEDULED traversal: a lane is between primitives (A), at an interior node (B) or at a leaf (C); each step
+//     the wave executes the body most lanes wait for.  A mesh's root-box test is an interior step on its root pair.
 #define AGPT_REFILL 20      // idle lanes that trigger a refill, closest-hit launches (tuned on C3: 16-24 equal)
 #define AGPT_REFILL_ANY 40  // same, any-hit / MIS-query launches: short traversals, refills are cheaper in bulk
 #define AGPT_RING 128  // entries of the per-wave ring of pre-filtered rays (power of two, >= 64 + 63)
@@ -226,12 +227,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     __syncthreads();
     const unsigned long long all_prims = n_prims >= 64 ? ~0ull : ((1ull << n_prims) - 1ull);
 
-    // work is reserved in ranges of `chunk` rays per atomic (a wave-private [next, end) window) and handed to idle
-    // lanes from there: one same-address atomic costs ~11 ns chip-wide, so per-refill atomics would cap the kernel
-    // at ~88 M refills/s.  The range shrinks for short queues so late, small launches still spread over the chip.
-    // Refills draw from ONE moving queue frontier (one atomic per refill): at any moment the whole chip traces rays
-    // that are neighbours in the queue (neighbouring pixels / path ids), which keeps their BVH nodes hot in the L2s.
-    // Reserving large private ranges per wave instead measured 8 % slower (A/B on MI355X, same process).
+    // Work distribution: rays are taken 64 at a time from the frontier of one of AGPT_FRONTIERS queue segments (see the
+    // refill code below); within a segment the frontier moves monotonically, so at any moment an XCD traces rays that are
+    // neighbours in the queue (neighbouring pixels / path ids), which keeps their BVH nodes hot in its L2.  Reserving large
+    // private ranges per wave instead measured 8 % slower (A/B on MI355X, same process).
     // A lane's scheduling state is carried by `cur` itself: CUR_IDLE = no ray, CUR_PICK = between meshes (state A),
     // anything below = an interior child-pair index (state B), sign bit set = a leaf encoding (state C).  One v_cmp per
     // state gives the wave's vote masks.
@@ -425,9 +424,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         if (act == 0) break;
 
         // ---- traversal round: vote scheduling -------------------------------------------------------------------
-        // Each lane is in one of three states: A = between meshes (pick the next primitive of its mask), B = at an
-        // interior node, C = at a leaf.  Every step the wave executes the body most lanes are waiting for (weighted by
-        // body cost); a lane's own sequence of operations is the reference's, only the interleaving between lanes
+        // Each lane is in one of three states: A = at a sphere / plane of its candidate list or at the list's end, B = at
+        // an interior node (or a mesh's root pair), C = at a leaf.  Every step the wave executes the body most lanes are
+        // waiting for; a lane's own sequence of operations is the reference's, only the interleaving between lanes
         // changes.  (A while-while loop makes every lane wait for the longest descent in the wave: 37 % active lanes.)
         for (;;) {
             const int nA = __popcll(__ballot(cur == CUR_PICK)), nB = __popcll(__ballot(cur < CUR_PICK)),
