@@ -1,15 +1,16 @@
 // agpt_kernels.h -- the gfx950 kernels of the wavefront path tracer.
 //
 // One agpt_render batch = S samples x NP tile pixels paths, path id = s*NP + p.  Per iteration:
-//     k_trace<closest>(ext queue)   continuation rays            -> hit[]
-//     k_trace<closest>(mis queue)   BSDF-sampled MIS rays        -> mis_hit[]
-//     k_trace<any>(shadow queue)    NEE shadow rays              -> occluded[]
-//     k_shade(active queue)         resolves the previous vertex' NEE, then PathTracer::Li's loop body for the
-//                                   new hit; appends to the next iteration's queues with one wave-aggregated
-//                                   atomic per queue per wave (ballot + prefix popcount compaction)
-// The trace kernels are persistent: a fixed grid of waves pulls 64-ray chunks off the queue with one atomic per
-// chunk; queue lengths stay on the device (no host round trip per iteration).  Path state is SoA float4 in HBM
-// (coalesced 16 B/lane); the per-lane traversal stack lives in LDS (32 entries x 4 B x 256 lanes = 32 KiB/block).
+//     k_trace_fast<0>(ext queue)     continuation rays, closest hit                     -> hit[]
+//     k_trace_fast<2>(mis queue)     BSDF-sampled MIS rays as exact early-exit queries  -> mis_ok[]
+//     k_trace_fast<1>(shadow queue)  NEE shadow rays, any hit                           -> occluded[]
+//     k_shade(active queue)          resolves the previous vertex' NEE, then PathTracer::Li's loop body for the
+//                                    new hit; appends to the next iteration's queues with one atomic per queue per
+//                                    1024-path tile (ballot counts, order-preserving offsets)
+// (the instrumented / fallback k_trace traces MIS rays as closest hits into mis_hit[]).  The trace kernels are
+// persistent: a fixed grid of waves pulls 64-ray chunks off the queue; queue lengths stay on the device (no host round
+// trip per iteration).  Path state is SoA float4 in HBM (coalesced 16 B/lane); the per-lane traversal stack lives in LDS
+// (32 entries x 4 B x 256 lanes = 32 KiB/block).
 #pragma once
 
 #include "agpt_shade.h"
