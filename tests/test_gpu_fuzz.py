@@ -1,6 +1,8 @@
 """Seeded random scenes: every primitive kind, material kind and light kind the path supports, mixed at random (including
 degenerate, tiny and huge triangles, overlapping spheres, multi-triangle leaves, sphere-only and light-less scenes, thin-lens
 cameras and varying MaxDepth), rendered and ray-cast on the GPU and compared with the oracle bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -75,11 +77,13 @@ def random_scene(seed):
     return d
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AGPT_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGPT_FUZZ_SEEDS", "24"))))
 def test_random_scene_matches_oracle(seed):
     d = random_scene(1000 + seed)
     rng = np.random.RandomState(seed)
     W, H, spp = int(rng.choice([24, 40, 64])), int(rng.choice([24, 36])), int(rng.choice([1, 3]))
+    if os.environ.get("AGPT_FUZZ_BIG"):
+        W, H, spp = 8 * W, 8 * H, 4
     depth = int(rng.choice([0, 1, 2, 5, 5, 8]))
     g = gpu_scene(d)
     o = oracle_scene(d, depth)
