@@ -274,9 +274,43 @@ private:
 
 // Integrator / PathTracer (integrator.h:28-31,120-196).  Li is evaluated for whole frames: one Render() call is
 // `spp` iterations of MyApp::Tick's per-pixel loop (myapp.cpp:161-175).
+// One rank's share of a film split over `world` GPUs: the 8-row blocks k with k % world == rank.
+// The rank's Accumulator then holds only its own rows, compacted (Accumulator(ctx, width, RowsOfRank(height, ...))).
+struct RankShare {
+    int block_rows = 8, world = 1, rank = 0;
+    // rows of a `film_height`-row film that belong to this rank
+    int Rows(int film_height) const {
+        int rows = 0;
+        for (int y0 = 0, k = 0; y0 < film_height; y0 += block_rows, k++)
+            if (k % world == rank) rows += (film_height - y0 < block_rows) ? film_height - y0 : block_rows;
+        return rows;
+    }
+};
+
 class PathTracer {
 public:
     explicit PathTracer(int maxDepth = 5) : MaxDepth(maxDepth) {}
+    // multi-GPU: `acc` is this rank's compact accumulator (width x share.Rows(film_height)); seeds depend on the global
+    // pixel index, so the gathered film is bit-identical to a single-GPU render
+    agpt_stats Render(Scene& scene, Accumulator& acc, int film_height, const RankShare& share, int spp, uint32_t seed_base = 0) const {
+        agpt_render_params p{};
+        p.width = acc.width;
+        p.height = film_height;
+        p.w = acc.width;
+        p.h = film_height;
+        p.spp_begin = acc.NumSamples();
+        p.spp_count = spp;
+        p.seed_base = seed_base;
+        p.max_depth = MaxDepth;
+        p.accum_pitch = acc.width;
+        p.interleave_block = share.block_rows;
+        p.interleave_world = share.world;
+        p.interleave_rank = share.rank;
+        agpt_stats st{};
+        check(agpt_render(scene.handle(), &p, acc.device_pixels(), &st), "agpt_render");
+        acc.AddSamples(spp);
+        return st;
+    }
     agpt_stats Render(Scene& scene, Accumulator& acc, int spp, uint32_t seed_base = 0) const {
         agpt_render_params p{};
         p.width = acc.width;

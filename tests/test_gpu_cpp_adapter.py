@@ -126,3 +126,56 @@ def test_bunny_scene_example_obj_orbit_png(tmp_path):
     lookat = np.float32([.5, 0, .5])
     assert abs(np.linalg.norm(lf - lookat) - np.linalg.norm(lf0 - lookat)) < 1e-3   # the orbit keeps the distance to lookat
     assert np.linalg.norm(lf - lf0) > 1.0                                             # and it did move
+
+
+@pytest.mark.gpu
+def test_cpp_rank_shares_reassemble_the_single_gpu_film(tmp_path):
+    """agpt::RankShare / PathTracer::Render(scene, acc, film_height, share, spp): three rank shares rendered one after the
+    other on one GPU and de-interleaved on the host equal the single-GPU film bit for bit."""
+    src = tmp_path / "shares.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "agpt_host.hpp"
+using namespace agpt;
+int main() {
+    const int W = 96, H = 70, spp = 3, world = 3;
+    Context ctx(0);
+    Scene scene(ctx);
+    int gold = DisneyMaterial::Make(scene, float3{0.944f, 0.776f, 0.373f}, .5f, 1.f);
+    int floor = DisneyMaterial::Make(scene, float3{.6f, .6f, .5f}, 1.f, 0.f);
+    scene.primitives_push_back(TriangleMesh::CreateBackdrop(float3{0, -1, 20}, float3{40, 20, 40}, 7.5f, 32), floor, 1);
+    scene.primitives_push_back(Sphere{float3{0, 0, 0}, 1.f}, gold);
+    scene.addAreaLight(Sphere{float3{0, 25, -20}, 1.f}, float3{200.f, 188.f, 183.f});
+    scene.lights_push_back(UniformInfiniteLight{float3{.4f, .45f, .5f}});
+    scene.camera = CameraDesc{{-1.46f, 1.16f, -4.64f}, {0, 0, 0}, {0, 1, 0}, float(W) / H, 45.f, 0.f};
+    scene.commit();
+    PathTracer pt;
+    Accumulator full(ctx, W, H);
+    pt.Render(scene, full, spp);
+    std::vector<float> ref = full.Download(), film((size_t)W * H * 4, 0.f);
+    for (int r = 0; r < world; r++) {
+        RankShare share{8, world, r};
+        const int rows = share.Rows(H);
+        Accumulator acc(ctx, W, rows);
+        pt.Render(scene, acc, H, share, spp);
+        std::vector<float> part = acc.Download();
+        // block j of this rank = film block k = r + j*world; inside a block the rows are flipped like AddSample does
+        int local = 0;
+        for (int y0 = 0, k = 0; y0 < H; y0 += 8, k++) {
+            const int h = H - y0 < 8 ? H - y0 : 8;
+            if (k % world != r) continue;
+            for (int i = 0; i < h; i++)   // local row (local + i) holds film y = y0 + h - 1 - i, i.e. accumulator row H-1-y
+                std::memcpy(&film[(size_t)(H - 1 - (y0 + h - 1 - i)) * W * 4], &part[(size_t)(local + i) * W * 4], (size_t)W * 16);
+            local += h;
+        }
+    }
+    std::printf("%s\n", std::memcmp(film.data(), ref.data(), film.size() * 4) == 0 ? "identical" : "DIFFERENT");
+    return 0;
+}''')
+    exe = str(tmp_path / "shares")
+    lib = ag.library_path()
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe, lib,
+                           "-Wl,-rpath," + os.path.dirname(lib)])
+    assert subprocess.check_output([exe]).decode().strip() == "identical"
