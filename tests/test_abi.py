@@ -66,6 +66,12 @@ def test_host_bvh_pinned_node_counts(oracle):
     v, n, t, idx = oracle.create_backdrop([0, -1, 20], [40, 20, 40], 7.5, 32)
     nodes, order, depth = ag.bvh_build(v, idx, 1)
     assert len(nodes) - 1 == 71
+    v, n, t, idx = oracle.pin_heightfield(361, 2.0)
+    nodes, order, depth = ag.bvh_build(v, idx, 1)
+    assert (len(nodes) - 1, depth) == (393989, 23)
+    v, n, t, idx = oracle.pin_heightfield(1581, 2.0)          # 4,999,122 triangles, multi-threaded build
+    nodes, order, depth = ag.bvh_build(v, idx, 1)
+    assert (len(nodes) - 1, depth) == (7465695, 28)
 
 
 def test_backdrop_matches_oracle(oracle):

@@ -100,3 +100,11 @@ def test_heightfield_260k_disney_ray_counts(oracle):
     (nn, leaves, maxd, avgd, maxleaf), st = heightfield_run(oracle, 361, 960, 540, True)
     assert (nn, maxd, "%.1f" % avgd, maxleaf) == (393989, 23, "18.0", 2)
     assert st.rays == 1526580 and st.outliers == 0
+
+
+def test_heightfield_5m_bvh_and_rays_per_sample(oracle):
+    """BASELINE.md section 2, third reference run: 4,999,122 triangles (1581 x 1581 quads), DisneyMaterial(.5, 0), 480 x 270 @ 1 spp:
+    7,465,695 BVH nodes, depth 28, average leaf depth 22.2, 2.95 rays per sample."""
+    (nn, leaves, maxd, avgd, maxleaf), st = heightfield_run(oracle, 1581, 480, 270, True)
+    assert (nn, maxd, "%.1f" % avgd) == (7465695, 28, "22.2")
+    assert "%.2f" % (st.rays / float(st.samples)) == "2.95" and st.outliers == 0
