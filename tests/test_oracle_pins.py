@@ -108,3 +108,14 @@ def test_heightfield_5m_bvh_and_rays_per_sample(oracle):
     (nn, leaves, maxd, avgd, maxleaf), st = heightfield_run(oracle, 1581, 480, 270, True)
     assert (nn, maxd, "%.1f" % avgd) == (7465695, 28, "22.2")
     assert "%.2f" % (st.rays / float(st.samples)) == "2.95" and st.outliers == 0
+
+
+def test_work_per_ray_matches_the_references_call_counts(oracle):
+    """BASELINE.md section 2 (gprof call counts of the reference, 70k + 260k runs pooled): about 49 Bounds::Intersect calls,
+    about 24 interior child-pair fetches and about 3.1 triangle tests per ray."""
+    (_, s1) = heightfield_run(oracle, 187, 1280, 720, False)
+    (_, s2) = heightfield_run(oracle, 361, 960, 540, True)
+    rays = float(s1.rays + s2.rays)
+    assert round((s1.box_tests + s2.box_tests) / rays) == 49
+    assert round((s1.interior_visits + s2.interior_visits) / rays) == 24
+    assert "%.1f" % ((s1.tri_tests + s2.tri_tests) / rays) == "3.1"
