@@ -432,12 +432,13 @@ class PathTracer:
                samples_per_batch=0, counters=False, timing=False, want_stats=True, interleave=None):
         """Adds `spp` samples per pixel of `tile` (x0, y0, w, h) into the DEVICE float4 buffer at accum_ptr.
         interleave=(block_rows, world, rank) renders this rank's row blocks of the whole film into its compact buffer
-        (see tiles.py) in one call."""
+        (see tiles.py) in one call.  counters: False/0 = off, True/1 = the reference-order instrumented kernel (the
+        reference recursion's visit counts), 2 = the production trace kernel counting the records it fetches itself."""
         x0, y0, w, h = tile if tile is not None else (0, 0, W, H)
         il = interleave if interleave is not None else (0, 0, 0)
         rp = RenderParams(W, H, x0, y0, w, h, spp_begin, spp, seed_base & 0xFFFFFFFF, self.MaxDepth,
                           accum_pitch if accum_pitch is not None else W, accum_row0, samples_per_batch,
-                          1 if counters else 0, 1 if timing else 0, il[0], il[1], il[2])
+                          int(counters), 1 if timing else 0, il[0], il[1], il[2])
         st = Stats()
         _check(scene.L.agpt_render(scene.h, C.byref(rp), C.c_void_p(int(accum_ptr)), C.byref(st) if want_stats else None),
                "agpt_render")

@@ -118,39 +118,51 @@ static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
 
 static int trace_grid(const agpt_ctx* c) { return c->num_cus * c->blocks_per_cu; }
 
-static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, bool count) {
-    return !count && sc.n_prims <= 64 * AGPT_MAX_CHUNKS && !c->force_generic;
+// count: 0 = off, 1 = reference-order counters (the generic kernel: what the reference's recursion does, equal to the
+// oracle's counters), 2 = the production kernel counting its own work (bench.py's roofline)
+static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, int count) {
+    return count != 1 && sc.n_prims <= 64 * AGPT_MAX_CHUNKS && !c->force_generic;
+}
+
+template <int MODE, int DEPTH, bool COUNT>
+static void launch_trace_fast(agpt_ctx* c, dim3 g, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr,
+                              uint32_t count_imm, uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits,
+                              uint32_t* occ, int refill) {
+    const dim3 block(AGPT_BLOCK);
+    if (sc.n_prims <= 64) {
+        hipLaunchKernelGGL((k_trace_fast<MODE, DEPTH, false, COUNT>), g, block, 0, c->stream, sc, queue, count_ptr, count_imm,
+                           work_head, ro, rd, hits, occ, c->counters.p, refill, 0);
+        return;
+    }
+    // more than 64 primitives: one launch per list-order chunk of 64 over the same queue
+    const int chunks = (sc.n_prims + 63) / 64;
+    for (int ch = 0; ch < chunks; ch++) {
+        if (ch > 0) (void)hipMemsetAsync(work_head, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream);
+        hipLaunchKernelGGL((k_trace_fast<MODE, DEPTH, true, COUNT>), g, block, 0, c->stream, sc, queue, count_ptr, count_imm,
+                           work_head, ro, rd, hits, occ, c->counters.p, refill, ch);
+    }
 }
 
 // MODE 0 closest, 1 any-hit, 2 MIS query (production kernel only; the generic kernel traces MIS rays as closest hits)
 template <int MODE>
 static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
-                         uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, bool count) {
+                         uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, int count) {
     constexpr bool ANY = MODE == 1;
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
     if (use_fast_trace(c, sc, count)) {
         const int refill = MODE == 0 ? c->refill : c->refill_any;
         const bool deep = sc.max_depth > AGPT_STACK_DEPTH;   // deep BVH: 64-entry stacks, half the blocks per CU
         const dim3 g = deep ? dim3(c->num_cus * 2) : grid;
-        if (sc.n_prims <= 64) {
-            if (!deep)
-                hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH, false>), g, block, 0, c->stream, sc, queue, count_ptr,
-                                   count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0);
+        if (!deep) {
+            if (count)
+                launch_trace_fast<MODE, AGPT_STACK_DEPTH, true>(c, g, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
             else
-                hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH_MAX, false>), g, block, 0, c->stream, sc, queue, count_ptr,
-                                   count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0);
+                launch_trace_fast<MODE, AGPT_STACK_DEPTH, false>(c, g, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
         } else {
-            // more than 64 primitives: one launch per list-order chunk of 64 over the same queue
-            const int chunks = (sc.n_prims + 63) / 64;
-            for (int ch = 0; ch < chunks; ch++) {
-                if (ch > 0) (void)hipMemsetAsync(work_head, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream);
-                if (!deep)
-                    hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH, true>), g, block, 0, c->stream, sc, queue, count_ptr,
-                                       count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, ch);
-                else
-                    hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_STACK_DEPTH_MAX, true>), g, block, 0, c->stream, sc, queue,
-                                       count_ptr, count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, ch);
-            }
+            if (count)
+                launch_trace_fast<MODE, AGPT_STACK_DEPTH_MAX, true>(c, g, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+            else
+                launch_trace_fast<MODE, AGPT_STACK_DEPTH_MAX, false>(c, g, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
         }
     } else if (sc.max_depth > AGPT_STACK_DEPTH) {
         dim3 grid_deep(c->num_cus * 2);
@@ -180,7 +192,7 @@ static hipEvent_t next_event(agpt_ctx* c) {
 template <int MODE>
 static void launch_trace_timed(agpt_ctx* c, bool timing, int kind, const DevScene& sc, const uint32_t* queue,
                                const uint32_t* count_ptr, uint32_t count_imm, uint32_t* work_head, const float4* ro,
-                               const float4* rd, DevHit* hits, uint32_t* occ, bool count) {
+                               const float4* rd, DevHit* hits, uint32_t* occ, int count) {
     if (timing) {
         (void)hipEventRecord(next_event(c), c->stream);
         c->tev_kind.push_back(kind);
@@ -613,7 +625,7 @@ int agpt_intersect_device(agpt_scene* s, const agpt_ray* d_rays, int n, agpt_hit
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     // stats requested -> the instrumented reference-order kernel (work counters); AGPT_INTERSECT_TIMING=1 (developer knob)
     // keeps the production kernel so that stats->trace_ms times it
-    const bool instrumented = stats != nullptr && !getenv("AGPT_INTERSECT_TIMING");
+    const int instrumented = (stats != nullptr && !getenv("AGPT_INTERSECT_TIMING")) ? 1 : 0;
     if (any_hit)
         launch_trace<1>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
                         instrumented);
@@ -702,7 +714,7 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         q[i].active = c->q[i][0].p; q[i].ext = c->q[i][1].p; q[i].mis = c->q[i][2].p; q[i].shadow = c->q[i][3].p;
         q[i].counts = c->qcounts.p + 4 * AGPT_QSTRIDE * i;
     }
-    const bool count = rp->enable_counters != 0;
+    const int count = rp->enable_counters == 2 ? 2 : (rp->enable_counters != 0 ? 1 : 0);
     const bool mis_mode = use_fast_trace(c, s->dev, count) && !c->mis_closest;
     const bool timing = rp->enable_timing != 0 && stats != nullptr;
     c->tev_used = 0;
@@ -770,6 +782,15 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
                          (double)d[0], (double)d[1], (double)d[2], 100 * d[0] / steps, 100 * d[1] / steps, 100 * d[2] / steps,
                          d[0] ? (double)d[3] / d[0] : 0., d[1] ? (double)d[4] / d[1] : 0., d[2] ? (double)d[5] / d[2] : 0.,
                          (double)d[6] / steps, (double)d[7], d[7] ? (double)d[8] / d[7] : 0., (double)d[9]);
+#ifdef AGPT_TRACE_CLOCK
+            const double tot = (double)dc.dbg[48 + mode];
+            std::fprintf(stderr,
+                         "[trace clock mode %d] wave-cycles %.4g: refill %.1f%%  vote %.1f%%  B %.1f%% (of which load wait %.1f%%)  C %.1f%%  A %.1f%%;"
+                         "  cycles per step: B %.0f (wait %.0f)  C %.0f  A %.0f  vote %.0f; per refill %.0f\n", mode, tot,
+                         100 * d[10] / tot, 100 * d[11] / tot, 100 * d[13] / tot, 100 * d[12] / tot, 100 * d[14] / tot, 100 * d[15] / tot,
+                         d[1] ? (double)d[13] / d[1] : 0., d[1] ? (double)d[12] / d[1] : 0., d[2] ? (double)d[14] / d[2] : 0.,
+                         d[0] ? (double)d[15] / d[0] : 0., (double)d[11] / steps, d[7] ? (double)d[10] / d[7] : 0.);
+#endif
         }
 #endif
         stats->samples = (uint64_t)NP * (uint64_t)rp->spp_count;

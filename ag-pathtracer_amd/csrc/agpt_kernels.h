@@ -80,13 +80,20 @@ __device__ __forceinline__ void pixel_of(const RenderConsts& rc, uint32_t p, int
 struct DevCounters {
     unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples, roots;
 #ifdef AGPT_TRACE_STATS
-    unsigned long long dbg[48];  // developer build only: wave-step statistics of k_trace_fast (tools/build_variant.py)
+    unsigned long long dbg[64];  // developer build only: wave-step statistics of k_trace_fast (tools/build_variant.py)
 #endif
 };
 #ifdef AGPT_TRACE_STATS
 #define TS(...) __VA_ARGS__
 #else
 #define TS(...)
+#endif
+// developer build only (-DAGPT_TRACE_STATS -DAGPT_TRACE_CLOCK): s_memtime stamps around the phases of k_trace_fast
+#ifdef AGPT_TRACE_CLOCK
+#define TCK(...) __VA_ARGS__
+#define TCK_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define TCK(...)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -192,7 +199,10 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 // queue (the candidate mask is one 64-bit word).  chunk > 0 continues where the previous launch stopped: a closest-hit
 // ray starts from its hit record so far, an any-hit / MIS ray that is already decided is skipped, and only a blocker is
 // written -- exactly Scene::Intersect's sequential walk with a shared ray.t (scene.h:5-19).
-template <int MODE, int DEPTH, bool CHUNKED>
+// COUNT: the same kernel also counts the work it does -- child-pair records fetched (interior), root-pair records fetched
+// (roots: the mesh root-box tests that survive the prefilter) and triangle tests -- for bench.py's roofline; the counts
+// are per-lane sums, deterministic for a given queue (every lane's own operation sequence is fixed).
+template <int MODE, int DEPTH, bool CHUNKED, bool COUNT>
 __global__ void __launch_bounds__(AGPT_BLOCK)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
@@ -285,10 +295,13 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     int mis_skip = -1;        // MODE 2: primitive index of the sampled area light's sphere (never a blocker itself)
     bool mis_reach = true;    // MODE 2: infinite light, or the ray reaches the light's sphere
     bool any_slow = false;                  // wave-uniform: some active lane's ray needs the true-division slab test
+    uint32_t c_int = 0, c_root = 0, c_tri = 0;   // COUNT
     TS(unsigned long long ts_steps[3] = {0, 0, 0}; unsigned long long ts_lanes[3] = {0, 0, 0}; unsigned long long ts_act = 0;
        unsigned long long ts_refills = 0; unsigned long long ts_refilled = 0; unsigned long long ts_pref = 0;)
+    TCK(unsigned long long tk_refill = 0, tk_vote = 0, tk_bmem = 0, tk_balu = 0, tk_c = 0, tk_a = 0; const unsigned long long tk_begin = TCK_NOW();)
 
     for (;;) {
+        TCK(const unsigned long long tk_r0 = TCK_NOW();)
         // ---- refill ---------------------------------------------------------------------------------------
         unsigned long long act = __ballot(cur != CUR_IDLE);
         const int n_active0 = __popcll(act);
@@ -422,6 +435,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             act = __ballot(cur != CUR_IDLE);
             any_slow = __ballot(cur != CUR_IDLE && !r.fast) != 0;
         }
+        TCK(tk_refill += TCK_NOW() - tk_r0;)
         if (act == 0) break;
 
         // ---- traversal round: vote scheduling -------------------------------------------------------------------
@@ -430,15 +444,18 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         // waiting for; a lane's own sequence of operations is the reference's, only the interleaving between lanes
         // changes.  (A while-while loop makes every lane wait for the longest descent in the wave: 37 % active lanes.)
         for (;;) {
+            TCK(const unsigned long long tk_v0 = TCK_NOW();)
             const int nA = __popcll(__ballot(cur == CUR_PICK)), nB = __popcll(__ballot(cur < CUR_PICK)),
                       nC = __popcll(__ballot((int32_t)cur < 0));
             const int n_active = nA + nB + nC;
             if (n_active == 0 || (n_active <= 64 - refill && !(exhausted && ring_head == ring_tail))) break;
+            TCK(const unsigned long long tk_v1 = TCK_NOW(); tk_vote += tk_v1 - tk_v0;)
             TS(ts_act += (unsigned long long)n_active; if (!(nB >= nA && nB >= nC) && !(nC >= nA)) { ts_steps[0]++; ts_lanes[0] += nA; })
             if (nB >= nA && nB >= nC) {
                 TS(ts_steps[1]++; ts_lanes[1] += nB;)
                 if (cur < CUR_PICK) {
                     const NodePair np = load_pair(sc, cur);
+                    TCK(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk_bmem += TCK_NOW() - tk_v1;)
                     float dl, dr;
                     bool hl, hr;
                     pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
@@ -446,6 +463,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
                     }
                     const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
+                    if (COUNT) {
+                        if (cur < rootpair_base) c_int++; else c_root++;
+                    }
                     hr = hr && cur < rootpair_base;   // a root pair has no right child
                     if (hl && hr) {
                         bool swap = ANY ? false : (dr < dl);
@@ -463,6 +483,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         cur = stack[sp * AGPT_BLOCK];
                     }
                 }
+                TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_balu += TCK_NOW() - tk_v1;)
             } else if (nC >= nA) {
                 TS(ts_steps[2]++; ts_lanes[2] += nC;)
                 if ((int32_t)cur < 0) {
@@ -473,6 +494,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
                         float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
                         float t, b1, b2;
+                        if (COUNT) c_tri++;
                         if (tri_test(V3(q0.x, q0.y, q0.z), V3(q1.x, q1.y, q1.z), V3(q2.x, q2.y, q2.z), r, rayt, t, b1, b2)) {
                             if (MIS) {
                                 if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
@@ -500,6 +522,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         cur = stack[sp * AGPT_BLOCK];
                     }
                 }
+                TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_c += TCK_NOW() - tk_v1;)
             } else if (cur == CUR_PICK) {
                 // end of the primitive list (retire), or the sphere / plane that is next in list order
                 if (mask == 0) {
@@ -543,6 +566,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                     if (cur == CUR_PICK) cur = pick_next(mask);   // (meshes never get here: pick_next routes them to B)
                 }
+                TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_a += TCK_NOW() - tk_v1;)
             }
         }
     }
@@ -550,7 +574,21 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         unsigned long long* d = counters->dbg + 16 * MODE;
         for (int k = 0; k < 3; ++k) { atomicAdd(d + k, ts_steps[k]); atomicAdd(d + 3 + k, ts_lanes[k]); }
         atomicAdd(d + 6, ts_act); atomicAdd(d + 7, ts_refills); atomicAdd(d + 8, ts_refilled); atomicAdd(d + 9, ts_pref);
+        TCK(atomicAdd(d + 10, tk_refill); atomicAdd(d + 11, tk_vote); atomicAdd(d + 12, tk_bmem); atomicAdd(d + 13, tk_balu);
+            atomicAdd(d + 14, tk_c); atomicAdd(d + 15, tk_a); atomicAdd(counters->dbg + 48 + MODE, TCK_NOW() - tk_begin);)
     })
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) {
+            c_int += __shfl_down(c_int, off);
+            c_root += __shfl_down(c_root, off);
+            c_tri += __shfl_down(c_tri, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters->interior, (unsigned long long)c_int);
+            atomicAdd(&counters->roots, (unsigned long long)c_root);
+            atomicAdd(&counters->tris, (unsigned long long)c_tri);
+        }
+    }
     if (threadIdx.x == 0 && blockIdx.x == 0 && !carry) {
         if (MODE == 1)
             atomicAdd(&counters->anyhit_rays, (unsigned long long)count);

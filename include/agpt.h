@@ -97,7 +97,9 @@ typedef struct {
     int32_t accum_row0;           /* film row (after the y flip) that accum's row 0 holds; tile rows map to
                                      accum row (H-1-y) - accum_row0 */
     int32_t samples_per_batch;    /* 0 = library default */
-    int32_t enable_counters;      /* 1 = also count interior visits / triangle tests (slower) */
+    int32_t enable_counters;      /* 1 = also count interior visits / triangle tests in the reference's order (the instrumented
+                                   * reference-order kernel, slower); 2 = the production trace kernel counts the work it
+                                   * does itself (child-pair / root-pair records fetched, triangle tests) */
     int32_t enable_timing;        /* 1 = bracket every trace launch with HIP events on the launch stream */
     /* multi-GPU row interleave (0 = off): of the film rows, cut into blocks of interleave_block rows, render only the
      * blocks k with k % interleave_world == interleave_rank (the tile must then be the whole film: x0=y0=0, w=W, h=H).

@@ -119,6 +119,9 @@ void oracle_create_backdrop(const float origin[3], const float size[3], float ra
 /* rgb2lin / hex2lin (template/common.h:29-39) */
 void oracle_hex2lin(int hex, float out[3]);
 void oracle_rgb2lin(const float in[3], float out[3]);
+/* Accumulator::CopyToSurface (myapp.h:34-41) with lin2rgb / rgb2uint (template/common.h:41-51):
+ * accum = n_pixels float4 sums (rgb + unused) -> 0x00RRGGBB */
+void oracle_copy_to_surface(const float* accum, int n_pixels, int samples, uint32_t* out);
 
 /* 0 = libm sinf/cosf/acosf (pinned against the reference outputs), 1 = correctly rounded through fp64 (what the HIP
  * kernels compute); see oracle.c */

@@ -85,6 +85,7 @@ def lib():
     L.oracle_set_trig_mode.argtypes = [C.c_int]
     L.oracle_hex2lin.argtypes = [C.c_int, fp]
     L.oracle_rgb2lin.argtypes = [fp, fp]
+    L.oracle_copy_to_surface.argtypes = [fp, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     _LIB = L
     return L
 
@@ -109,6 +110,15 @@ def rgb2lin(rgb):
     a, p = _f(rgb)
     out = np.zeros(3, np.float32)
     lib().oracle_rgb2lin(p, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def copy_to_surface(accum, samples):
+    """Accumulator::CopyToSurface: accum[..., 4] float sums -> uint32 0x00RRGGBB per pixel (same leading shape)."""
+    a, p = _f(accum)
+    assert a.shape[-1] == 4
+    out = np.zeros(a.shape[:-1], np.uint32)
+    lib().oracle_copy_to_surface(p, int(out.size), int(samples), out.ctypes.data_as(C.POINTER(C.c_uint32)))
     return out
 
 
@@ -267,8 +277,17 @@ class OracleScene:
 TRIG_LIBM, TRIG_CORRECTLY_ROUNDED = 0, 1
 
 
+_TRIG_MODE = TRIG_LIBM
+
+
 def set_trig_mode(mode):
+    global _TRIG_MODE
     lib().oracle_set_trig_mode(int(mode))
+    _TRIG_MODE = int(mode)
+
+
+def get_trig_mode():
+    return _TRIG_MODE
 
 
 def wang_hash(s):

@@ -165,6 +165,23 @@ void oracle_hex2lin(int hex, float out[3]) {
     oracle_rgb2lin(rgb, out);
 }
 
+/* Accumulator::CopyToSurface (myapp.h:34-41): for every pixel lin2rgb(pixels[i] / (float)samples) -> rgb2uint
+ * (template/common.h:41-51).  lin2rgb: pow(c, e) with float e = 1 / 2.2f (float overload = powf); rgb2uint:
+ * clamp(clr.x, 0.0, 0.999) binds to the float overload (precomp.h:678) = fmaxf(a, fminf(f, b)) with the template's
+ * comparators, so a NaN channel (negative or NaN sum) quantises to 255; then static_cast<int>(256 * c) and
+ * (r << 16) + (g << 8) + b.  accum: n_pixels float4 (rgb + unused), the layout oracle_render writes. */
+void oracle_copy_to_surface(const float* accum, int n_pixels, int samples, uint32_t* out) {
+    float e = 1 / 2.2f;
+    for (int i = 0; i < n_pixels; i++) {
+        float cx = accum[4 * i] / (float)samples, cy = accum[4 * i + 1] / (float)samples, cz = accum[4 * i + 2] / (float)samples;
+        float rx = powf(cx, e), ry = powf(cy, e), rz = powf(cz, e);
+        int r = (int)(256 * t_clampf(rx, 0.0f, 0.999f));
+        int g = (int)(256 * t_clampf(ry, 0.0f, 0.999f));
+        int b = (int)(256 * t_clampf(rz, 0.0f, 0.999f));
+        out[i] = (uint32_t)((r << 16) + (g << 8) + b);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Types: Ray (camera.h:3-15), materials (material.h), SurfaceInteraction (intersectable.h:63-115),
  * BSDF (reflection.h:83-201)
