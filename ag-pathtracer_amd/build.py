@@ -12,7 +12,11 @@ HEADERS = ["agpt_math.h", "agpt_scene.h", "agpt_trace.h", "agpt_shade.h", "agpt_
 # explicit __builtin_fmaf calls (Markstein division in agpt_trace.h) stay fused.
 # -fno-slp-vectorize: the SLP pass packs adjacent f32 adds/muls into v_pk_*_f32, which on gfx950 cost more than the two
 # scalar ops they replace (measured: trace -1 %, shade -2.5 % with the pass off).
+# -amdgpu-atomic-optimizer-strategy=None: the pass rewrites a one-lane atomicAdd into "atomic + readfirstlane of its result
+# right behind it", which makes the trace kernel's pipelined work-queue atomic synchronous again; every atomic in this
+# library is already aggregated by hand (one lane per wave / per tile).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
          "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 

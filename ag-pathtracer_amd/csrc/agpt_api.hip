@@ -97,7 +97,7 @@ struct agpt_scene {
     bool has_camera = false;
     bool committed = false;
     int max_depth = 0;
-    DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade;
+    DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade, d_prefilter;
     DevBuf<uint32_t> d_bigleaves;
     DevBuf<DevPrim> d_prims;
     DevBuf<DevMaterial> d_materials;
@@ -277,6 +277,7 @@ void agpt_scene_destroy(agpt_scene* s) {
     s->d_bigleaves.release();
     s->d_tri_verts.release();
     s->d_tri_shade.release();
+    s->d_prefilter.release();
     s->d_prims.release();
     s->d_materials.release();
     s->d_lights.release();
@@ -445,6 +446,7 @@ int agpt_scene_commit(agpt_scene* s) {
     if ((rc = upload(s->d_bigleaves, flat.bigleaves, st))) return rc;
     if ((rc = upload(s->d_tri_verts, flat.tri_verts, st))) return rc;
     if ((rc = upload(s->d_tri_shade, flat.tri_shade, st))) return rc;
+    if ((rc = upload(s->d_prefilter, flat.prefilter, st))) return rc;
     if ((rc = upload(s->d_prims, flat.prims, st))) return rc;
     if ((rc = upload(s->d_materials, s->materials, st))) return rc;
     if ((rc = upload(s->d_lights, lights, st))) return rc;
@@ -482,6 +484,9 @@ int agpt_scene_commit(agpt_scene* s) {
     s->dev.max_depth = flat.max_depth;
     s->dev.rootpair_base = flat.rootpair_base;
     for (int ch = 0; ch < AGPT_MAX_CHUNKS; ch++) s->dev.mesh_masks[ch] = flat.mesh_masks[ch];
+    for (int ch = 0; ch < AGPT_MAX_CHUNKS; ch++) s->dev.analytic_masks[ch] = flat.analytic_masks[ch];
+    for (int ch = 0; ch <= AGPT_MAX_CHUNKS; ch++) s->dev.pf_begin[ch] = flat.pf_begin[ch];
+    s->dev.prefilter = s->d_prefilter.p;
     s->dev.n_meshes = 0;
     for (const DevPrim& dp : flat.prims)
         if (dp.type == AGPT_PRIM_MESH && dp.n_tris > 0) s->dev.n_meshes++;

@@ -533,6 +533,24 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
         }
         out.prims.push_back(dp);
     }
+    // prefilter table + analytic-primitive masks of the production trace kernel (agpt_scene.h)
+    out.prefilter.clear();
+    for (int c = 0; c <= AGPT_MAX_CHUNKS; c++) out.pf_begin[c] = 0;
+    for (int c = 0; c < AGPT_MAX_CHUNKS; c++) {
+        out.analytic_masks[c] = 0;
+        out.pf_begin[c] = (int32_t)(out.prefilter.size() / 2);
+        for (size_t pi = 64 * (size_t)c; pi < std::min<size_t>(out.prims.size(), 64 * (size_t)(c + 1)); pi++) {
+            const DevPrim& dp = out.prims[pi];
+            if (dp.type != AGPT_PRIM_MESH)
+                out.analytic_masks[c] |= 1ull << (pi % 64);
+            else if (dp.n_tris > 0) {
+                out.prefilter.push_back(F4(dp.root_bmin[0], dp.root_bmin[1], dp.root_bmin[2], bits((uint32_t)(pi % 64))));
+                out.prefilter.push_back(F4(dp.root_bmax[0], dp.root_bmax[1], dp.root_bmax[2], 0.f));
+            }
+        }
+    }
+    out.pf_begin[AGPT_MAX_CHUNKS] = (int32_t)(out.prefilter.size() / 2);
+    if (out.prefilter.empty()) out.prefilter.assign(2, F4(0, 0, 0, 0));
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -69,6 +69,10 @@ struct FlatScene {
     int max_depth = 0;
     uint32_t rootpair_base = 0;        // node index of primitive 0's root pair (agpt_scene.h)
     unsigned long long mesh_masks[AGPT_MAX_CHUNKS] = {};  // non-empty meshes, one word per chunk of 64 primitives
+    unsigned long long analytic_masks[AGPT_MAX_CHUNKS] = {};  // spheres and planes, same layout
+    // prefilter table (agpt_scene.h): two float4 per non-empty mesh in list order, chunk c = records [pf_begin[c], pf_begin[c+1])
+    std::vector<float4> prefilter;
+    int32_t pf_begin[AGPT_MAX_CHUNKS + 1] = {};
 };
 // per-mesh concatenation + per-triangle precomputation (trianglemesh.cpp:46-111's ray-independent part)
 void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSphere>& spheres,

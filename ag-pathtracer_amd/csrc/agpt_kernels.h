@@ -96,6 +96,11 @@ struct DevCounters {
 #define TCK(...)
 #endif
 
+// Wave-uniform bookkeeping values that the compiler cannot prove uniform (loop-carried through regions with per-lane
+// branches) are pinned to scalar registers with readfirstlane: they then cost SALU instead of VALU + exec-mask juggling.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+
 // ---------------------------------------------------------------------------------------------------------
 // wave-aggregated queue append: one atomic per wave, order inside the wave preserved
 __device__ __forceinline__ void queue_push(uint32_t* q, uint32_t* count, bool pred, uint32_t value) {
@@ -217,7 +222,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     uint32_t* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t count = count_ptr ? *count_ptr : count_imm;
+    // (a value loaded through a pointer counts as divergent for the compiler: readfirstlane keeps the bookkeeping scalar)
+    const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)(count_ptr ? *count_ptr : count_imm));
     const int n_prims = CHUNKED ? (sc.n_prims - prim_base < 64 ? sc.n_prims - prim_base : 64) : sc.n_prims;
     if ((int)threadIdx.x < n_prims) {
         const DevPrim& P = sc.prims[prim_base + threadIdx.x];
@@ -272,7 +278,18 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         }
         return CUR_PICK;
     };
-    bool exhausted = false;  // wave-uniform
+    // Work distribution and the refill pipeline.  The queue is cut into AGPT_FRONTIERS contiguous segments, each with its own
+    // frontier counter on its own 128-B line; a wave starts in the segment of its XCD (workgroups are dealt round-robin to
+    // the 8 XCDs) and moves on to the next segment when its own is drained.  (One shared counter was the limit of the
+    // any-hit launches: same-address atomics complete one per ~11 ns chip-wide.)  Getting 64 new rays is a chain of four
+    // dependent memory operations -- frontier atomic -> queue[] -> ray_o/ray_d[] -> (prefilter) -> ring -- that took
+    // 10-20 k cycles per top-up when run back to back (13 % of the closest-hit launches' wave time, 30 % of the MIS
+    // launches', measured with s_memtime stamps).  It is therefore software-pipelined over successive top-ups:
+    // pump_consume() prefilters the rays whose loads were issued one top-up earlier into the ring; pump_issue() -- called
+    // AFTER the idle lanes have been handed their rays, because vector-memory results return in issue order and anything
+    // loaded after it would wait for it -- issues the ray loads for the path ids fetched by the previous pump_issue, the
+    // queue load for the offset returned by the previous atomic, and the next atomic.  The traversal steps between two
+    // top-ups hide all of it; only a cold pipeline (kernel start, segment change) runs the chain synchronously.
     uint32_t seg = blockIdx.x & (AGPT_FRONTIERS - 1u), segs_left = AGPT_FRONTIERS;   // wave-uniform
     const uint32_t seg_len = ((count + AGPT_FRONTIERS - 1u) / AGPT_FRONTIERS + 63u) & ~63u;
     uint32_t pid = 0, cur = CUR_IDLE, hid = AGPT_HIT_MISS;
@@ -300,91 +317,160 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
        unsigned long long ts_refills = 0; unsigned long long ts_refilled = 0; unsigned long long ts_pref = 0;)
     TCK(unsigned long long tk_refill = 0, tk_vote = 0, tk_bmem = 0, tk_balu = 0, tk_c = 0, tk_a = 0; const unsigned long long tk_begin = TCK_NOW();)
 
+    uint32_t pfa_off = 0;       // lane 0: offset returned by the pending frontier atomic (stage A)
+    uint32_t pfa_seg = 0;
+    bool pfa_valid = false;     // wave-uniform, like every *_valid / *_n below
+    uint32_t pfb_pid = 0, pfb_n = 0;   // stage B: path ids of the chunk after next (queue load pending)
+    bool pfb_valid = false;
+    uint32_t pfc_pid = 0, pfc_n = 0;   // stage C: the next chunk's rays (ray loads pending)
+    bool pfc_valid = false;
+    float4 pfc_o, pfc_d;
+    pfc_o.x = pfc_o.y = pfc_o.z = pfc_o.w = 0.f;
+    pfc_d = pfc_o;
+    auto drained = [&]() -> bool { return segs_left == 0 && !pfa_valid && !pfb_valid && !pfc_valid; };
+    auto pin_state = [&]() {   // see uni(): keeps the bookkeeping in scalar registers
+        seg = uni(seg); segs_left = uni(segs_left); ring_tail = uni(ring_tail); ring_head = uni(ring_head);
+        pfa_seg = uni(pfa_seg); pfa_valid = uni(pfa_valid); pfb_n = uni(pfb_n); pfb_valid = uni(pfb_valid);
+        pfc_n = uni(pfc_n); pfc_valid = uni(pfc_valid);
+    };
+    auto pump_consume = [&]() {
+        // stage C -> ring: conservative per-primitive prefilter of the 64 rays that arrived, all lanes busy
+        if (pfc_valid) {
+            if ((uint32_t)lane < pfc_n) {
+                const uint32_t npid = pfc_pid;
+                float4 o = pfc_o;
+                const float4 d = pfc_d;
+                const TraceRay nr = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
+                unsigned long long skip_bit = 0;
+                bool decided = false;  // chunk > 0: nothing in this chunk can change the ray's answer any more
+                if (MIS) {   // MIS rays carry the sampled light's sphere (primitive index, ~0u = infinite light) in o.w; tmax = inf
+                    const uint32_t shape = __float_as_uint(o.w);
+                    o.w = AGPT_FLT_MAX;
+                    if (shape != 0xFFFFFFFFu) {
+                        v3 lc;
+                        float lr2, ts;
+                        light_sphere((int)shape, lc, lr2);
+                        if (sphere_test_c(lc, lr2, nr, o.w, ts)) o.w = ts;
+                        const int ls = (int)shape - prim_base;
+                        if (!CHUNKED || (ls >= 0 && ls < 64)) skip_bit = 1ull << ls;
+                    }
+                }
+                if (carry) {
+                    if (MODE == 0)
+                        o.w = hits[npid].t;
+                    else
+                        decided = MODE == 1 ? occluded[npid] != 0u : occluded[npid] == 0u;
+                }
+                // t ~ fma(b, R, -RN(O*R)) differs from the exact quotient (b-O)/D by at most 2^-23 |t| + 2^-24 |O*R|
+                // (R = RN(1/D), one rounding of O*R, one of the fma); rejecting only when tmax*(1+2e-6) + 2E < tmin with
+                // E = 2^-22 max|O*R| can therefore only over-accept -- the exact Bounds::Intersect still decides where the
+                // reference runs it.
+                const float nox = -(nr.O.x * nr.R.x), noy = -(nr.O.y * nr.R.y), noz = -(nr.O.z * nr.R.z);
+                const float slack2 = 0x1p-21f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
+                // The records come through SCALAR loads (wave-uniform index, constant address space: scene arrays are
+                // read-only for the whole launch, and only loads from that address space are selected as s_load without a
+                // no-clobber proof), so the box coordinates are SGPR operands of the FMAs and the loads of several records
+                // are in flight at once; reading the LDS copy made every iteration wait for its own two ds_reads.
+                unsigned long long m = 0;
+                typedef const float __attribute__((address_space(4))) ConstF;
+                typedef const DevPrim __attribute__((address_space(4))) ConstPrim;
+                ConstF* pf = (ConstF*)sc.prefilter;
+                const int j0 = sc.pf_begin[CHUNKED ? chunk : 0], j1 = sc.pf_begin[(CHUNKED ? chunk : 0) + 1];
+#pragma unroll 4
+                for (int j = j0; j < j1; ++j) {   // non-empty meshes: conservative slab test of the root box
+                    ConstF* q = pf + 8 * j;   // (bmin.xyz, bit index), (bmax.xyz, -)
+                    float t0x = __builtin_fmaf(q[0], nr.R.x, nox), t1x = __builtin_fmaf(q[4], nr.R.x, nox);
+                    float t0y = __builtin_fmaf(q[1], nr.R.y, noy), t1y = __builtin_fmaf(q[5], nr.R.y, noy);
+                    float t0z = __builtin_fmaf(q[2], nr.R.z, noz), t1z = __builtin_fmaf(q[6], nr.R.z, noz);
+                    float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
+                    float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), o.w));
+                    const bool h = !(__builtin_fmaf(tmax, 1.000002f, slack2) < tmin);
+                    m |= (unsigned long long)(h ? 1u : 0u) << __float_as_uint(q[3]);
+                }
+                ConstPrim* pr = (ConstPrim*)(sc.prims + prim_base);
+                for (unsigned long long am = sc.analytic_masks[CHUNKED ? chunk : 0]; am; am &= am - 1) {   // spheres, planes: exact
+                    const int k = __ffsll((long long)am) - 1;
+                    ConstPrim& P = pr[k];
+                    float root;
+                    const bool sphere = P.type == AGPT_PRIM_SPHERE;
+                    if (analytic_test(sphere ? 1.f : 3.f, V3(P.cx, P.cy, P.cz), sphere ? P.r2 : P.r, P.r2, nr, o.w, root)) m |= 1ull << k;
+                }
+                const uint32_t slot = (ring_tail + (uint32_t)lane) & (AGPT_RING - 1);
+                ring_pid[slot] = npid;
+                ring_mask[slot] = decided ? 0ull : ((nr.fast ? m : all_prims) & ~skip_bit);
+            }
+            ring_tail += pfc_n;
+            pfc_valid = false;
+            TS(ts_pref++;)
+        }
+        pin_state();
+    };
+    // Loads are issued for all 64 lanes (indices clamped to valid entries): exec-mask branches around them would make
+    // the compiler's s_waitcnt placement conservative (vmcnt(0) at every merge).
+    auto pump_issue = [&]() {
+        // (1) everything that READS a value loaded earlier comes first ...
+        const uint32_t last = count ? count - 1u : 0u;
+        const bool adv_b = pfb_valid, adv_a = pfa_valid;
+        uint32_t b_pid = pfb_pid, offv = pfa_off;
+        const uint32_t b_n = pfb_n;
+        // one unconditional touch of every register a pending load may still target: the waits for them land HERE on every
+        // path (free in the steady state: those loads were issued a whole top-up ago), not behind the new loads below;
+        // it also keeps the readfirstlane of the atomic's result from being hoisted up to the atomic
+        asm volatile("" : "+v"(b_pid), "+v"(offv) : "v"(pfc_o.x), "v"(pfc_d.x));
+        bool in_range = false;
+        uint32_t base = 0, n_new = 0;
+        if (adv_a) {   // the frontier atomic has returned: where is that chunk (or is the segment drained)?
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)offv);
+            const uint32_t seg_begin = pfa_seg * seg_len;
+            const uint32_t seg_end = seg_begin + seg_len < count ? seg_begin + seg_len : count;
+            in_range = seg_begin < seg_end && off < seg_end - seg_begin;
+            base = in_range ? seg_begin + off : 0u;
+            n_new = in_range ? (seg_end - base < 64u ? seg_end - base : 64u) : 0u;
+            if (!in_range && segs_left > 0) {
+                --segs_left;
+                seg = (seg + 1u) & (AGPT_FRONTIERS - 1u);
+            }
+        }
+        // (2) ... then the new loads, back to back, with no use of a loaded value in between: a merge of branches with
+        // different numbers of outstanding loads makes the compiler wait with vmcnt(0), i.e. for the loads just issued
+        if (adv_b) {   // B -> C: fetch the rays of the path ids that have arrived
+            pfc_pid = b_pid;
+            pfc_n = b_n;
+            pfc_o = ray_o[b_pid];
+            pfc_d = ray_d[b_pid];
+            pfc_valid = true;
+        }
+        pfb_valid = false;
+        if (adv_a) {   // A -> B: fetch that chunk's path ids
+            uint32_t idx = base + (uint32_t)lane;
+            idx = idx < last ? idx : last;
+            pfb_pid = queue ? queue[idx] : idx;
+            pfb_n = n_new;
+            pfb_valid = in_range;
+        }
+        pfa_valid = false;
+        if (segs_left > 0) {   // A: reserve the next 64 queue entries of the current segment
+            if (lane == 0) pfa_off = atomicAdd(work_head + seg * AGPT_QSTRIDE, 64u);
+            pfa_seg = seg;
+            pfa_valid = true;
+        }
+        pin_state();
+    };
+
     for (;;) {
         TCK(const unsigned long long tk_r0 = TCK_NOW();)
+        pin_state();
+        any_slow = uni(any_slow);
         // ---- refill ---------------------------------------------------------------------------------------
         unsigned long long act = __ballot(cur != CUR_IDLE);
         const int n_active0 = __popcll(act);
-        if (n_active0 <= 64 - refill && !(exhausted && ring_head == ring_tail)) {
+        if (n_active0 <= 64 - refill && !(drained() && ring_head == ring_tail)) {
             const uint32_t n_idle = (uint32_t)(64 - n_active0);
-            // top the ring up from the single global queue frontier: phase A runs for 64 NEW rays with all lanes busy
-            while (ring_tail - ring_head < n_idle && !exhausted) {
-                // The queue is cut into AGPT_FRONTIERS contiguous segments, each with its own frontier counter on its own
-                // 128-B line; a wave starts in the segment of its XCD (workgroups are dealt round-robin to the 8 XCDs) and
-                // moves on to the next segment when its own is drained.  One shared counter was the limit of the any-hit
-                // launches: same-address atomics complete one per ~11 ns chip-wide, 7.8 M of them per launch set = 86 ms.
-                // Per-XCD frontiers also keep every L2 on its own neighbourhood of the queue.
-                uint32_t base = 0, n_new = 0;
-                for (;;) {
-                    const uint32_t seg_begin = seg * seg_len;
-                    const uint32_t seg_end = seg_begin + seg_len < count ? seg_begin + seg_len : count;
-                    uint32_t off = 0;
-                    if (lane == 0) off = atomicAdd(work_head + seg * AGPT_QSTRIDE, 64u);
-                    off = __shfl(off, 0);
-                    if (seg_begin < seg_end && off < seg_end - seg_begin) {
-                        base = seg_begin + off;
-                        n_new = seg_end - base < 64u ? seg_end - base : 64u;
-                        break;
-                    }
-                    if (--segs_left == 0) {
-                        exhausted = true;
-                        break;
-                    }
-                    seg = (seg + 1u) & (AGPT_FRONTIERS - 1u);
-                }
-                if ((uint32_t)lane < n_new) {
-                    const uint32_t npid = queue ? queue[base + lane] : base + lane;
-                    float4 o = ray_o[npid];
-                    const float4 d = ray_d[npid];
-                    const TraceRay nr = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
-                    unsigned long long skip_bit = 0;
-                    bool decided = false;  // chunk > 0: nothing in this chunk can change the ray's answer any more
-                    if (carry) {
-                        if (MODE == 0)
-                            o.w = hits[npid].t;
-                        else
-                            decided = MODE == 1 ? occluded[npid] != 0u : occluded[npid] == 0u;
-                    }
-                    if (MIS) {
-                        const DevLight& lt = sc.lights[__float_as_uint(d.w)];
-                        if (lt.type == AGPT_LIGHT_AREA) {
-                            v3 lc;
-                            float lr2, ts;
-                            light_sphere(lt.shape, lc, lr2);
-                            if (sphere_test_c(lc, lr2, nr, o.w, ts)) o.w = ts;
-                            const int ls = lt.shape - prim_base;
-                            if (!CHUNKED || (ls >= 0 && ls < 64)) skip_bit = 1ull << ls;
-                        }
-                    }
-                    // phase A: conservative per-primitive filter at the initial t.  t ~ fma(b, R, -RN(O*R)) differs from
-                    // the exact quotient (b-O)/D by at most 2^-23 |t| + 2^-24 |O*R| (R = RN(1/D), one rounding of O*R, one
-                    // of the fma); rejecting only when tmax*(1+2e-6) + 2E < tmin with E = 2^-22 max|O*R| can therefore
-                    // only over-accept -- the exact Bounds::Intersect still decides where the reference runs it.
-                    const float nox = -(nr.O.x * nr.R.x), noy = -(nr.O.y * nr.R.y), noz = -(nr.O.z * nr.R.z);
-                    const float slack2 = 0x1p-21f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
-                    unsigned long long m = 0;
-                    for (int k = 0; k < n_prims; ++k) {
-                        const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
-                        bool h;
-                        if (pa.w == 1.f || pa.w == 3.f) {
-                            float root;
-                            h = analytic_test(pa.w, V3(pa.x, pa.y, pa.z), pb2.x, pb2.y, nr, o.w, root);
-                        } else {
-                            float t0x = __builtin_fmaf(pa.x, nr.R.x, nox), t1x = __builtin_fmaf(pb2.x, nr.R.x, nox);
-                            float t0y = __builtin_fmaf(pa.y, nr.R.y, noy), t1y = __builtin_fmaf(pb2.y, nr.R.y, noy);
-                            float t0z = __builtin_fmaf(pa.z, nr.R.z, noz), t1z = __builtin_fmaf(pb2.z, nr.R.z, noz);
-                            float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
-                            float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), o.w));
-                            h = pa.w == 0.f && !(__builtin_fmaf(tmax, 1.000002f, slack2) < tmin);
-                        }
-                        m |= (unsigned long long)(h ? 1u : 0u) << k;
-                    }
-                    const uint32_t slot = (ring_tail + (uint32_t)lane) & (AGPT_RING - 1);
-                    ring_pid[slot] = npid;
-                    ring_mask[slot] = decided ? 0ull : ((nr.fast ? m : all_prims) & ~skip_bit);
-                }
-                ring_tail += n_new;
-                TS(ts_pref++;)
+            // top the ring up: one pump_consume() per 64 rays in the steady state; a cold pipeline is pumped synchronously
+            if (ring_tail - ring_head < n_idle && pfc_valid) pump_consume();
+            while (ring_tail - ring_head < n_idle && !drained()) {
+                pump_issue();
+                pump_consume();
             }
             // hand ring entries to idle lanes (same wave wrote them: a wave barrier orders the LDS writes and reads)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -405,13 +491,14 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         mis_area = false;
                         mis_skip = -1;
                         mis_reach = true;
-                        const DevLight& lt = sc.lights[__float_as_uint(d.w)];
-                        if (lt.type == AGPT_LIGHT_AREA) {
+                        const uint32_t shape = __float_as_uint(o.w);   // the sampled light's sphere, ~0u = infinite light
+                        rayt = AGPT_FLT_MAX;
+                        if (shape != 0xFFFFFFFFu) {
                             v3 lc;
                             float lr2, ts;
-                            light_sphere(lt.shape, lc, lr2);
+                            light_sphere((int)shape, lc, lr2);
                             mis_area = true;
-                            mis_skip = lt.shape - prim_base;   // position in this chunk's numbering (may lie outside it)
+                            mis_skip = (int)shape - prim_base;   // position in this chunk's numbering (may lie outside it)
                             mis_reach = sphere_test_c(lc, lr2, r, rayt, ts);
                             if (mis_reach) rayt = ts;
                         }
@@ -432,6 +519,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             }
             ring_head += take;
             TS(ts_refills++; ts_refilled += take;)
+            if (!pfc_valid && !drained()) pump_issue();   // refill the emptied stage: nothing below waits for these loads
             act = __ballot(cur != CUR_IDLE);
             any_slow = __ballot(cur != CUR_IDLE && !r.fast) != 0;
         }
@@ -448,7 +536,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             const int nA = __popcll(__ballot(cur == CUR_PICK)), nB = __popcll(__ballot(cur < CUR_PICK)),
                       nC = __popcll(__ballot((int32_t)cur < 0));
             const int n_active = nA + nB + nC;
-            if (n_active == 0 || (n_active <= 64 - refill && !(exhausted && ring_head == ring_tail))) break;
+            if (n_active == 0 || (n_active <= 64 - refill && !(drained() && ring_head == ring_tail))) break;
             TCK(const unsigned long long tk_v1 = TCK_NOW(); tk_vote += tk_v1 - tk_v0;)
             TS(ts_act += (unsigned long long)n_active; if (!(nB >= nA && nB >= nC) && !(nC >= nA)) { ts_steps[0]++; ts_lanes[0] += nA; })
             if (nB >= nA && nB >= nC) {
@@ -697,8 +785,17 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
 
 __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderConsts& rc, const PathBuffers& pb, uint32_t pid) {
     uint32_t bits = 0;
+    // Every per-path record is fetched up front, unconditionally: the loads then overlap in one memory round trip instead
+    // of forming a chain of dependent ones behind the flag tests (a record that turns out not to be needed is a coalesced
+    // 16-B read of a valid slot -- every path id owns a slot in every array).
     float4 b4 = pb.beta4[pid];
     float4 l4 = pb.L4[pid];
+    const float4 f4 = pb.fac4[pid];
+    const uint32_t was_occluded = pb.occluded[pid];
+    const uint32_t was_mis_ok = pb.mis_ok[pid];
+    const float4 c1_4 = pb.c1[pid], c2_4 = pb.c2[pid];
+    const DevHit h = pb.hit[pid];
+    const float4 o4 = pb.ext_o[pid], d4 = pb.ext_d[pid];
     v3 beta = V3(b4.x, b4.y, b4.z);
     v3 L = V3(l4.x, l4.y, l4.z);
     uint32_t flags = __float_as_uint(b4.w);
@@ -706,19 +803,17 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 
     // ---- resolve the previous vertex' UniformSampleOneLight (integrator.h:38-105) ------------------
     if (flags & PF_PENDING) {
-        float4 f4 = pb.fac4[pid];
         v3 Ld = V3s(0.f);
         if (flags & PF_PEND_C1) {
-            if (!pb.occluded[pid]) {  // VisibilityTester::Unoccluded, lights.cpp:10-12
-                float4 c = pb.c1[pid];
-                Ld = Ld + V3(c.x, c.y, c.z);
+            if (!was_occluded) {  // VisibilityTester::Unoccluded, lights.cpp:10-12
+                Ld = Ld + V3(c1_4.x, c1_4.y, c1_4.z);
             }
         }
         if (flags & PF_PEND_C2) {
             uint32_t light = __float_as_uint(f4.w);
             bool add;
             if (rc.mis_mode) {
-                add = pb.mis_ok[pid] != 0;
+                add = was_mis_ok != 0;
             } else if (uint32_t hid = pb.mis_hit[pid].id; hid != AGPT_HIT_MISS) {  // integrator.h:82-85: hit shape's area light must be the sampled light
                 int hp = (hid & AGPT_HIT_SPHERE) ? (int)(hid & 0x7FFFFFFFu)
                                                  : (int)__float_as_uint(sc.tri_shade[4 * (size_t)hid + 3].w);
@@ -726,10 +821,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             } else {  // :86-87 light.Le(ray): non-zero only for an IsInfinite() light
                 add = sc.lights[light].type != AGPT_LIGHT_AREA;
             }
-            if (add) {
-                float4 c = pb.c2[pid];
-                Ld = Ld + V3(c.x, c.y, c.z);
-            }
+            if (add) Ld = Ld + V3(c2_4.x, c2_4.y, c2_4.z);
         }
         float lightPdf = 1.f / sc.n_lights;           // integrator.h:100,104
         L = L + beta * (Ld / lightPdf);               // integrator.h:166
@@ -739,8 +831,6 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 
     if (!(flags & PF_DEAD)) {
         uint32_t bounces = flags & PF_BOUNCE_MASK;
-        DevHit h = pb.hit[pid];
-        float4 o4 = pb.ext_o[pid], d4 = pb.ext_d[pid];
         v3 O = V3(o4.x, o4.y, o4.z), D = V3(d4.x, d4.y, d4.z);
         const bool found = h.id != AGPT_HIT_MISS;
         Surface s;
@@ -789,6 +879,9 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             float uS0 = 0.f, uS1 = 0.f;
             float scatteringPdf = 0;
             v3 wi = V3s(0.f);
+            bool light_ok = false;
+            float nee_lightPdf = 0, nee_visT = 0;
+            v3 nee_Li = V3s(0.f), nee_visO = V3s(0.f), nee_visD = V3(0, 0, 1);
             if (do_nee) {
                 int nLights = sc.n_lights;
                 numLight = (int)(rng_float(rng) * nLights);
@@ -834,44 +927,95 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                         Li = mat_v3(light.L);
                     }
                 }
-                if (lightPdf > 0 && !isblack(Li)) {  // integrator.h:44-60
-                    v3 f;
-                    bsdf_f_pdf(bsdf, m, wc, s.wo, wi, true, &f, &scatteringPdf);
+                light_ok = lightPdf > 0 && !isblack(Li);   // integrator.h:44
+                nee_lightPdf = lightPdf;
+                nee_Li = Li;
+                nee_visO = visO;
+                nee_visD = visD;
+                nee_visT = visT;
+            }
+            // ---- the three BSDF evaluations of a vertex run through ONE loop with one evaluator call site:
+            //   it 0: BSDF::f + BSDF::Pdf for the light sample          (integrator.h:46-47, reflection.h:114-123,174-188)
+            //   it 1: EstimateDirect's BSDF-sampling leg, uScattering   (integrator.h:63-90,  BSDF::Sample_f reflection.h:124-172)
+            //   it 2: the continuation                                   (integrator.h:170-187, BSDF::Sample_f)
+            v3 fac = V3s(1.f);
+            const v3 wo_l = w2l(bsdf, s.wo);
+            const float woDotNg = dot(s.wo, bsdf.ng);
+#pragma unroll 1
+            for (int it = do_nee ? (light_ok ? 0 : 1) : 2; it < 3; ++it) {
+                const uint32_t lmask = lobes_matching(bsdf, it < 2);   // skipSpecular for both EstimateDirect evaluations
+                const int matching = __popc(lmask);
+                float pdf = it == 1 ? scatteringPdf : 0.f;   // EstimateDirect reuses its scatteringPdf variable (quirk 9)
+                v3 f = V3s(0.f), wi_l = V3s(0.f);
+                int skip_lobe = -1;
+                bool eval = false, sampledSpecular = false;
+                if (it == 0) {   // bsdf_f_pdf's prologue
+                    if (bsdf.lobes != 0 && wo_l.z != 0) {
+                        wi_l = w2l(bsdf, wi);
+                        eval = true;
+                    }
+                } else {         // bsdf_sample_f's prologue
+                    float u0, u1;
+                    if (it == 1) {
+                        u0 = uS0;
+                        u1 = uS1;
+                    } else {
+                        wi = V3s(0.f);
+                        u0 = rng_float(rng);
+                        u1 = rng_float(rng);
+                    }
+                    if (matching == 0) {
+                        pdf = 0;
+                    } else {
+                        int comp = (int)floorf(u0 * matching);
+                        if (matching - 1 < comp) comp = matching - 1;
+                        uint32_t mm = lmask;   // the comp-th matching lobe in list order
+                        for (int i = 0; i < comp; ++i) mm &= mm - 1;
+                        const int lobe = __ffs((int)mm) - 1;
+                        const float ur0 = sminf(u0 * matching - comp, AGPT_ONE_MINUS_EPS);
+                        if (wo_l.z != 0) {   // (wo.z == 0: returns 0 with the caller's pdf untouched, quirk 9)
+                            pdf = 0;
+                            sampledSpecular = lobe == LOBE_SPECULAR;
+                            const v3 fs = lobe_sample(m, lobe, wo_l, &wi_l, ur0, u1, &pdf, wc);
+                            if (pdf != 0) {
+                                wi = l2w(bsdf, wi_l);
+                                if (lobe == LOBE_SPECULAR) {
+                                    if (matching > 1) pdf /= matching;
+                                    f = fs;
+                                } else {
+                                    eval = true;   // pdf += the other lobes' Pdf (list order), f = sum of all matching lobes' f
+                                    skip_lobe = matching > 1 ? lobe : -2;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (eval) {
+                    const bool reflect = dot(wi, bsdf.ng) * woDotNg > 0;
+                    const LobeEval e = bsdf_eval_lobes_inl(m, lmask, wo_l, wi_l, skip_lobe, pdf, reflect, wc);
+                    if (it == 0)
+                        pdf = matching > 0 ? e.pdf / matching : 0.f;
+                    else if (matching > 1)
+                        pdf = e.pdf / matching;
+                    if (reflect) f = e.f;
+                }
+                if (it == 0) {   // integrator.h:46-60
+                    scatteringPdf = pdf;
                     f = f * absdot(wi, s.ns);
                     if (!isblack(f)) {
-                        float weight = power_heuristic(1, lightPdf, 1, scatteringPdf);
-                        v3 c1 = f * Li * weight / lightPdf;
+                        float weight = power_heuristic(1, nee_lightPdf, 1, scatteringPdf);
+                        v3 c1 = f * nee_Li * weight / nee_lightPdf;
                         float4 c4, so4, sd4;
                         c4.x = c1.x; c4.y = c1.y; c4.z = c1.z; c4.w = 0.f;
-                        so4.x = visO.x; so4.y = visO.y; so4.z = visO.z; so4.w = visT;
-                        sd4.x = visD.x; sd4.y = visD.y; sd4.z = visD.z; sd4.w = 0.f;
+                        so4.x = nee_visO.x; so4.y = nee_visO.y; so4.z = nee_visO.z; so4.w = nee_visT;
+                        sd4.x = nee_visD.x; sd4.y = nee_visD.y; sd4.z = nee_visD.z; sd4.w = 0.f;
                         pb.c1[pid] = c4;
                         pb.sh_o[pid] = so4;
                         pb.sh_d[pid] = sd4;
                         flags |= PF_PEND_C1;
                         bits |= SB_SHADOW;
                     }
-                }
-            }
-            // ---- the two BSDF-sampling legs share one copy of the code: leg 0 = EstimateDirect's MIS leg
-            // (integrator.h:63-90, uScattering, skipSpecular), leg 1 = the continuation (integrator.h:170-187)
-            v3 fac = V3s(1.f);
-#pragma unroll 1
-            for (int leg = do_nee ? 0 : 1; leg < 2; ++leg) {
-                float u0, u1;
-                float pdf = 0;
-                if (leg == 0) {
-                    u0 = uS0;
-                    u1 = uS1;
-                    pdf = scatteringPdf;  // EstimateDirect reuses its scatteringPdf variable (quirk 9)
-                } else {
-                    wi = V3s(0.f);
-                    u0 = rng_float(rng);
-                    u1 = rng_float(rng);
-                }
-                bool sampledSpecular = false;
-                v3 f = bsdf_sample_f(bsdf, m, wc, s.wo, &wi, u0, u1, &pdf, leg == 0, &sampledSpecular);
-                if (leg == 0) {
+                } else if (it == 1) {   // integrator.h:63-90
                     const DevLight& light = sc.lights[numLight];
                     f = f * absdot(wi, s.ns);
                     if (!isblack(f) && pdf > 0) {
@@ -894,7 +1038,10 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                             v3 mD = normalize(wi);
                             float4 c4, mo4, md4;
                             c4.x = c2.x; c4.y = c2.y; c4.z = c2.z; c4.w = 0.f;
-                            mo4.x = mO.x; mo4.y = mO.y; mo4.z = mO.z; mo4.w = AGPT_FLT_MAX;
+                            // tmax = FLT_MAX; the MIS-query kernel (mis_mode 1) is told the sampled light's sphere in its place
+                            mo4.x = mO.x; mo4.y = mO.y; mo4.z = mO.z;
+                            mo4.w = rc.mis_mode ? __uint_as_float(light.type == AGPT_LIGHT_AREA ? (uint32_t)light.shape : 0xFFFFFFFFu)
+                                                : AGPT_FLT_MAX;
                             md4.x = mD.x; md4.y = mD.y; md4.z = mD.z; md4.w = __uint_as_float((uint32_t)numLight);
                             pb.c2[pid] = c4;
                             pb.mis_o[pid] = mo4;
@@ -903,7 +1050,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                             bits |= SB_MIS;
                         }
                     }
-                } else if (isblack(f) || pdf == 0) {
+                } else if (isblack(f) || pdf == 0) {   // integrator.h:175
                     flags |= PF_DEAD;
                 } else {
                     fac = f * absdot(wi, s.ns) / pdf;

@@ -79,8 +79,11 @@ AGPT_HD float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 AGPT_HD void cr_sincosf(float xf, float* s, float* c) {
     const double x = (double)xf;
     if (!(fabs(x) <= 8.0)) {
-        *s = (float)sin(x);
-        *c = (float)cos(x);
+        // Not reachable from the hot path (every caller's argument range is listed above); NaN and +-inf arguments give NaN
+        // like sin / cos.  A generic-range fallback here was inlined into every caller -- ~500 cold fp64 instructions and the
+        // register peak of k_shade each.
+        *s = __builtin_nanf("");
+        *c = __builtin_nanf("");
         return;
     }
     const double kd = rint(x * 0.63661977236758134308);

@@ -111,6 +111,12 @@ struct DevScene {
     // 64c + k if it is such a mesh.
     uint32_t rootpair_base;
     unsigned long long mesh_masks[AGPT_MAX_CHUNKS];   // per chunk of 64 primitives
+    unsigned long long analytic_masks[AGPT_MAX_CHUNKS];   // spheres and planes, same layout
+    // Prefilter table: per non-empty mesh in list order two float4 -- (root bmin.xyz, bit index in its chunk), (root
+    // bmax.xyz, -) -- read through scalar loads by the trace kernel's conservative per-primitive filter; chunk c owns the
+    // records [pf_begin[c], pf_begin[c + 1]).
+    const float4* prefilter;
+    int32_t pf_begin[AGPT_MAX_CHUNKS + 1];
     DevCamera cam;
 };
 

@@ -239,10 +239,11 @@ __device__ __forceinline__ LobeEval lobe_eval(const DevMaterial& m, int lobe, v3
 // Sum of f and of Pdf over the lobes of `mask`, in list order: what BSDF::f (reflection.h:114-123, when reflect),
 // BSDF::Pdf (:174-188) and the tail of BSDF::Sample_f (:156-170) compute.  `skip_pdf_lobe` (or -1) is left out of the
 // pdf sum (the sampled lobe contributes the pdf its own Sample_f returned), pdf_init is the running value.
-// One shared, non-inlined copy: keeps k_shade inside the instruction cache.
-__device__ __noinline__ LobeEval bsdf_eval_lobes(const DevMaterial* mp, uint32_t mask, v3 wo, v3 wi, int skip_pdf_lobe,
-                                                 float pdf_init, bool want_f, WoCache wc) {
-    const DevMaterial& m = *mp;
+// k_shade has exactly ONE call site of the inlined form (its three evaluations per vertex run through one loop), so
+// the code stays inside the instruction cache without a function call -- a call forces everything live across it into
+// the callee-saved registers and was the main source of the kernel's scratch spills.
+__device__ __forceinline__ LobeEval bsdf_eval_lobes_inl(const DevMaterial& m, uint32_t mask, v3 wo, v3 wi, int skip_pdf_lobe,
+                                                        float pdf_init, bool want_f, WoCache wc) {
     LobeEval acc;
     acc.f = V3s(0.f);
     acc.pdf = pdf_init;
@@ -254,6 +255,11 @@ __device__ __noinline__ LobeEval bsdf_eval_lobes(const DevMaterial* mp, uint32_t
         if (lobe != skip_pdf_lobe) acc.pdf += e.pdf;
     }
     return acc;
+}
+// shared non-inlined copy for the helpers below (known-answer kernels)
+__device__ __noinline__ LobeEval bsdf_eval_lobes(const DevMaterial* mp, uint32_t mask, v3 wo, v3 wi, int skip_pdf_lobe,
+                                                 float pdf_init, bool want_f, WoCache wc) {
+    return bsdf_eval_lobes_inl(*mp, mask, wo, wi, skip_pdf_lobe, pdf_init, want_f, wc);
 }
 
 // ---- BSDF (reflection.cpp:6-11, reflection.h:83-201) --------------------------------------------------------

@@ -65,23 +65,34 @@ def render_sharded(render_block, W, H, rank, world, local_accum, block_rows=BLOC
     return out
 
 
-def gather_to_rank0(local_accum, W, H, rank, world, block_rows=BLOCK_ROWS):
+def alloc_gather_buffers(local_accum, rank, world):
+    """Receive buffers of gather_to_rank0 on rank 0 (None elsewhere and for world == 1): allocate once, outside any
+    timed region, and pass as out_bufs."""
+    import torch.distributed as dist
+    if world == 1 or rank != 0:
+        return None
+    if dist.is_initialized() and dist.get_backend() == "gloo" and local_accum.is_cuda:
+        host = local_accum.cpu()
+        return [host.new_zeros(host.shape) for _ in range(world)]
+    return [local_accum.new_zeros(local_accum.shape) for _ in range(world)]
+
+
+def gather_to_rank0(local_accum, W, H, rank, world, block_rows=BLOCK_ROWS, out_bufs=None):
     """One collective: gather every rank's compact buffer to rank 0 and de-interleave.  Uses torch.distributed
-    (backend nccl = RCCL for GPU tensors, gloo for CPU tensors).  Returns the full accumulator on rank 0, else None."""
+    (backend nccl = RCCL for GPU tensors, gloo for CPU tensors).  Returns the full accumulator on rank 0, else None.
+    out_bufs: rank 0's receive buffers from alloc_gather_buffers (allocated here when None)."""
     import torch.distributed as dist
     if world == 1:
         return deinterleave([local_accum], W, H, 1, block_rows)
+    bufs = out_bufs if out_bufs is not None else alloc_gather_buffers(local_accum, rank, world)
     # dist.gather on the nccl backend is RCCL grouped send/recv: every peer's buffer (<= 17 MB at 4K) travels its own
     # direct xGMI link to rank 0, so the exchange is not ring-bound.
     if dist.get_backend() == "gloo" and local_accum.is_cuda:
         # rehearsal path (several ranks on one GPU): gloo gathers through host memory
-        host = local_accum.cpu()
-        bufs = [host.new_zeros(host.shape) for _ in range(world)] if rank == 0 else None
-        dist.gather(host, bufs, dst=0)
+        dist.gather(local_accum.cpu(), bufs, dst=0)
         if rank != 0:
             return None
         return deinterleave([b.to(local_accum.device) for b in bufs], W, H, world, block_rows)
-    bufs = [local_accum.new_zeros(local_accum.shape) for _ in range(world)] if rank == 0 else None
     dist.gather(local_accum, bufs, dst=0)
     if rank != 0:
         return None
