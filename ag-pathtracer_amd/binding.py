@@ -31,6 +31,7 @@ EXPORTS = [
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
     "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
     "agpt_obj_free", "agpt_obj_last_error", "agpt_write_png", "agpt_write_pfm",
+    "agpt_comm_unique_id", "agpt_comm_init", "agpt_comm_destroy", "agpt_gather_tiles", "agpt_deinterleave_tiles",
 ]
 
 
@@ -131,6 +132,12 @@ def lib():
     L.agpt_obj_get.argtypes = [vp, fp, fp, fp, ip]
     L.agpt_obj_free.argtypes = [vp]
     L.agpt_obj_free.restype = None
+    L.agpt_comm_unique_id.argtypes = [vp]
+    L.agpt_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.agpt_comm_destroy.argtypes = [vp]
+    L.agpt_comm_destroy.restype = None
+    L.agpt_gather_tiles.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.agpt_deinterleave_tiles.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.agpt_obj_last_error.restype = C.c_char_p
     _LIB = L
     return L
@@ -263,11 +270,43 @@ class Context:
                                    C.byref(seed)), "agpt_kat_rng")
         return out, seed.value
 
+    def deinterleave_tiles(self, compact_ptr, W, H, block_rows, world, rank, full_ptr):
+        _check(self.L.agpt_deinterleave_tiles(self.h, C.c_void_p(int(compact_ptr)), W, H, block_rows, world, rank, C.c_void_p(int(full_ptr))),
+               "agpt_deinterleave_tiles")
+
     def resolve(self, accum_ptr, n_pixels, samples):
         out = np.zeros(n_pixels, np.uint32)
         _check(self.L.agpt_resolve(self.h, C.c_void_p(accum_ptr), n_pixels, samples,
                                    out.ctypes.data_as(C.POINTER(C.c_uint32))), "agpt_resolve")
         return out
+
+
+def comm_unique_id():
+    """agpt_comm_unique_id: 128 bytes (ncclUniqueId) that rank 0 hands to the other ranks."""
+    buf = C.create_string_buffer(128)
+    _check(lib().agpt_comm_unique_id(C.cast(buf, C.c_void_p)), "agpt_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """agpt_comm: the RCCL communicator of a multi-GPU render (one rank per process / GPU)."""
+
+    def __init__(self, ctx, world=1, rank=0, unique_id=None):
+        self.ctx = ctx
+        self.L = ctx.L
+        h = C.c_void_p()
+        idp = C.c_char_p(unique_id) if unique_id is not None else None
+        _check(self.L.agpt_comm_init(ctx.h, C.cast(idp, C.c_void_p) if idp else None, int(world), int(rank), C.byref(h)), "agpt_comm_init")
+        self.h = h
+
+    def gather_tiles(self, local_ptr, W, H, block_rows, full_ptr):
+        _check(self.L.agpt_gather_tiles(self.h, C.c_void_p(int(local_ptr)), W, H, block_rows, C.c_void_p(int(full_ptr) if full_ptr else 0)),
+               "agpt_gather_tiles")
+
+    def close(self):
+        if self.h:
+            self.L.agpt_comm_destroy(self.h)
+            self.h = None
 
 
 def write_png(path, rgb_words, width, height):

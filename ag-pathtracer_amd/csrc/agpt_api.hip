@@ -83,6 +83,17 @@ struct agpt_ctx {
     std::vector<hipEvent_t> tev;
     size_t tev_used = 0;
     std::vector<int> tev_kind;  // 0 = closest (continuation), 1 = closest (MIS), 2 = any-hit
+    // first error of an asynchronous helper (memset / event record / kernel launch inside the launch helpers); checked and
+    // cleared by the entry point that enqueued the work
+    hipError_t deferred = hipSuccess;
+    void note(hipError_t e) {
+        if (e != hipSuccess && deferred == hipSuccess) deferred = e;
+    }
+    hipError_t take_deferred() {
+        const hipError_t e = deferred;
+        deferred = hipSuccess;
+        return e;
+    }
 };
 
 struct agpt_scene {
@@ -108,6 +119,16 @@ struct agpt_scene {
     DevScene dev{};
 };
 
+// scoped device allocation for the entry points that need a temporary: freed on every return path
+template <class T>
+struct TempBuf {
+    T* p = nullptr;
+    ~TempBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t count) { return hipMalloc((void**)&p, (count ? count : 1) * sizeof(T)); }
+};
+
 template <class T>
 static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
     int rc = buf.ensure(host.empty() ? 1 : host.size());
@@ -125,10 +146,10 @@ static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, int count) {
 }
 
 template <int MODE, int DEPTH, bool COUNT>
-static void launch_trace_fast(agpt_ctx* c, dim3 g, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr,
-                              uint32_t count_imm, uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits,
-                              uint32_t* occ, int refill) {
-    const dim3 block(AGPT_BLOCK);
+static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
+                              uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, int refill) {
+    // 32-entry stacks: 40 KiB of LDS per block, four blocks per CU; 64-entry stacks (BVHs deeper than 32): two per CU
+    const dim3 block(AGPT_BLOCK), g(c->num_cus * (DEPTH <= AGPT_STACK_DEPTH ? c->blocks_per_cu : 2));
     if (sc.n_prims <= 64) {
         hipLaunchKernelGGL((k_trace_fast<MODE, DEPTH, false, COUNT>), g, block, 0, c->stream, sc, queue, count_ptr, count_imm,
                            work_head, ro, rd, hits, occ, c->counters.p, refill, 0);
@@ -137,10 +158,20 @@ static void launch_trace_fast(agpt_ctx* c, dim3 g, const DevScene& sc, const uin
     // more than 64 primitives: one launch per list-order chunk of 64 over the same queue
     const int chunks = (sc.n_prims + 63) / 64;
     for (int ch = 0; ch < chunks; ch++) {
-        if (ch > 0) (void)hipMemsetAsync(work_head, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream);
+        if (ch > 0) c->note(hipMemsetAsync(work_head, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
         hipLaunchKernelGGL((k_trace_fast<MODE, DEPTH, true, COUNT>), g, block, 0, c->stream, sc, queue, count_ptr, count_imm,
                            work_head, ro, rd, hits, occ, c->counters.p, refill, ch);
     }
+}
+
+template <int MODE, int DEPTH>
+static void launch_trace_fast_c(agpt_ctx* c, int count, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr,
+                                uint32_t count_imm, uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits,
+                                uint32_t* occ, int refill) {
+    if (count)
+        launch_trace_fast<MODE, DEPTH, true>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+    else
+        launch_trace_fast<MODE, DEPTH, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
 }
 
 // MODE 0 closest, 1 any-hit, 2 MIS query (production kernel only; the generic kernel traces MIS rays as closest hits)
@@ -151,19 +182,10 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
     if (use_fast_trace(c, sc, count)) {
         const int refill = MODE == 0 ? c->refill : c->refill_any;
-        const bool deep = sc.max_depth > AGPT_STACK_DEPTH;   // deep BVH: 64-entry stacks, half the blocks per CU
-        const dim3 g = deep ? dim3(c->num_cus * 2) : grid;
-        if (!deep) {
-            if (count)
-                launch_trace_fast<MODE, AGPT_STACK_DEPTH, true>(c, g, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
-            else
-                launch_trace_fast<MODE, AGPT_STACK_DEPTH, false>(c, g, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
-        } else {
-            if (count)
-                launch_trace_fast<MODE, AGPT_STACK_DEPTH_MAX, true>(c, g, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
-            else
-                launch_trace_fast<MODE, AGPT_STACK_DEPTH_MAX, false>(c, g, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
-        }
+        if (sc.max_depth <= AGPT_STACK_DEPTH)
+            launch_trace_fast_c<MODE, AGPT_STACK_DEPTH>(c, count, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        else
+            launch_trace_fast_c<MODE, AGPT_STACK_DEPTH_MAX>(c, count, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
     } else if (sc.max_depth > AGPT_STACK_DEPTH) {
         dim3 grid_deep(c->num_cus * 2);
         if (count)
@@ -183,7 +205,7 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
 static hipEvent_t next_event(agpt_ctx* c) {
     if (c->tev_used == c->tev.size()) {
         hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
+        c->note(hipEventCreate(&e));
         c->tev.push_back(e);
     }
     return c->tev[c->tev_used++];
@@ -194,11 +216,12 @@ static void launch_trace_timed(agpt_ctx* c, bool timing, int kind, const DevScen
                                const uint32_t* count_ptr, uint32_t count_imm, uint32_t* work_head, const float4* ro,
                                const float4* rd, DevHit* hits, uint32_t* occ, int count) {
     if (timing) {
-        (void)hipEventRecord(next_event(c), c->stream);
+        c->note(hipEventRecord(next_event(c), c->stream));
         c->tev_kind.push_back(kind);
     }
     launch_trace<MODE>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, count);
-    if (timing) (void)hipEventRecord(next_event(c), c->stream);
+    c->note(hipGetLastError());
+    if (timing) c->note(hipEventRecord(next_event(c), c->stream));
 }
 
 extern "C" {
@@ -585,6 +608,20 @@ int agpt_device_upload(agpt_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 
 // ---- hot path -----------------------------------------------------------------------------------------------
+// bytes of pool state per path: 11 float4 arrays + 2 hit arrays (16 B) + 2 flag words + 8 queue words
+#define AGPT_BYTES_PER_PATH (11 * 16 + 2 * 16 + 2 * 4 + 8 * 4)
+static void release_pool(agpt_ctx* c) {
+    for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4, &c->c1,
+                              &c->c2})
+        b->release();
+    c->hit.release();
+    c->mis_hit.release();
+    c->occluded.release();
+    c->mis_ok.release();
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 4; j++) c->q[i][j].release();
+    c->pool_paths = 0;
+}
 static int ensure_pool(agpt_ctx* c, size_t paths) {
     int rc;
     for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4,
@@ -642,6 +679,7 @@ int agpt_intersect_device(agpt_scene* s, const agpt_ray* d_rays, int n, agpt_hit
                        d_out);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(c->take_deferred());
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         DevCounters dc;
@@ -662,22 +700,15 @@ int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* o
     if (n == 0) return AGPT_OK;
     agpt_ctx* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    agpt_ray* d_rays = nullptr;
-    agpt_hit* d_out = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * sizeof(agpt_ray)));
-    if (hipMalloc((void**)&d_out, (size_t)n * sizeof(agpt_hit)) != hipSuccess) {
-        (void)hipFree(d_rays);
+    TempBuf<agpt_ray> d_rays;
+    TempBuf<agpt_hit> d_out;
+    if (d_rays.alloc((size_t)n) != hipSuccess || d_out.alloc((size_t)n) != hipSuccess)
         return fail(AGPT_ERR_NOMEM, "agpt_intersect_batch: out of device memory");
-    }
-    int rc = AGPT_OK;
-    if (hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(agpt_ray), hipMemcpyHostToDevice, c->stream) != hipSuccess)
-        rc = fail(AGPT_ERR_DEVICE, "agpt_intersect_batch: upload failed");
-    if (rc == AGPT_OK) rc = agpt_intersect_device(s, d_rays, n, d_out, any_hit, stats);
-    if (rc == AGPT_OK && hipMemcpy(out, d_out, (size_t)n * sizeof(agpt_hit), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(AGPT_ERR_DEVICE, "agpt_intersect_batch: download failed");
-    (void)hipFree(d_rays);
-    (void)hipFree(d_out);
-    return rc;
+    HIP_TRY(hipMemcpyAsync(d_rays.p, rays, (size_t)n * sizeof(agpt_ray), hipMemcpyHostToDevice, c->stream));
+    int rc = agpt_intersect_device(s, d_rays.p, n, d_out.p, any_hit, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * sizeof(agpt_hit), hipMemcpyDeviceToHost));
+    return AGPT_OK;
 }
 
 int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, agpt_stats* stats) {
@@ -705,7 +736,23 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     int S = rp->samples_per_batch > 0 ? rp->samples_per_batch : (int)std::max<uint64_t>(1, (128ull << 20) / NP);
     S = std::min(S, std::max(1, rp->spp_count));
     if ((uint64_t)NP * (uint64_t)S > 0x7FFFFFFFull) return fail(AGPT_ERR_LIMIT, "agpt_render: batch too large");
+    // The batch is a performance choice, not a semantic one (the image is batch-split invariant): when the pool has to
+    // grow, keep it within the memory that is actually free (other ranks or applications may share the GPU), and halve
+    // the batch if an allocation still fails.
+    if ((size_t)NP * (size_t)S > c->pool_paths) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t avail = free_b + c->pool_paths * (size_t)AGPT_BYTES_PER_PATH;
+            const size_t fit = (size_t)((double)avail * 0.9) / (size_t)AGPT_BYTES_PER_PATH;
+            while (S > 1 && (size_t)NP * (size_t)S > fit) S = (S + 1) / 2;
+        }
+    }
     int rc = ensure_pool(c, (size_t)NP * S);
+    while (rc == AGPT_ERR_NOMEM && S > 1) {
+        release_pool(c);
+        S = (S + 1) / 2;
+        rc = ensure_pool(c, (size_t)NP * S);
+    }
     if (rc) return rc;
     s->dev.cam = s->cam;
 
@@ -728,6 +775,8 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     uint64_t iterations = 0, launches = 0;
     const int shade_grid = c->num_cus * 8;
+    const bool shade_lds_tables = s->dev.n_prims <= AGPT_SHADE_LDS_PRIMS && s->dev.n_materials <= AGPT_SHADE_LDS_MATERIALS &&
+                                  s->dev.n_lights <= AGPT_SHADE_LDS_LIGHTS && !getenv("AGPT_SHADE_GLOBAL_TABLES");
 
     for (int s0 = rp->spp_begin; s0 < rp->spp_begin + rp->spp_count; s0 += S) {
         RenderConsts rcn;
@@ -760,7 +809,10 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
             else
                 launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
             launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
-            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
+            if (shade_lds_tables)
+                hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
+            else
+                hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
             cur = nxt;
             iterations++;
             launches += 3;
@@ -770,6 +822,7 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(c->take_deferred());
     if (stats) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         std::memset(stats, 0, sizeof(*stats));
@@ -822,12 +875,12 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
 int agpt_resolve(agpt_ctx* c, const float* accum_dev, int n_pixels, int samples, uint32_t* out_rgb) {
     if (!c || !accum_dev || !out_rgb || n_pixels <= 0 || samples <= 0) return fail(AGPT_ERR_INVALID, "agpt_resolve: bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    uint32_t* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, (size_t)n_pixels * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, c->stream, (const float4*)accum_dev, n_pixels, samples, d);
-    HIP_TRY(hipMemcpyAsync(out_rgb, d, (size_t)n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    TempBuf<uint32_t> d;
+    HIP_TRY(d.alloc((size_t)n_pixels));
+    hipLaunchKernelGGL(k_resolve, dim3((n_pixels + 255) / 256), dim3(256), 0, c->stream, (const float4*)accum_dev, n_pixels, samples, d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rgb, d.p, (size_t)n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipFree(d));
     return AGPT_OK;
 }
 
@@ -837,18 +890,18 @@ int agpt_kat_bsdf_eval(agpt_scene* s, int material, int n, const float* wo3, con
         return fail(AGPT_ERR_INVALID, "agpt_kat_bsdf_eval: bad argument");
     agpt_ctx* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    float *d_wo, *d_wi, *d_f, *d_p;
-    HIP_TRY(hipMalloc((void**)&d_wo, 12 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_wi, 12 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_f, 12 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_p, 4 * (size_t)n));
-    HIP_TRY(hipMemcpy(d_wo, wo3, 12 * (size_t)n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_wi, wi3, 12 * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat_bsdf_eval, dim3((n + 63) / 64), dim3(64), 0, c->stream, s->dev, material, n, d_wo, d_wi, d_f, d_p);
+    TempBuf<float> d_wo, d_wi, d_f, d_p;
+    HIP_TRY(d_wo.alloc(3 * (size_t)n));
+    HIP_TRY(d_wi.alloc(3 * (size_t)n));
+    HIP_TRY(d_f.alloc(3 * (size_t)n));
+    HIP_TRY(d_p.alloc((size_t)n));
+    HIP_TRY(hipMemcpy(d_wo.p, wo3, 12 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_wi.p, wi3, 12 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_bsdf_eval, dim3((n + 63) / 64), dim3(64), 0, c->stream, s->dev, material, n, d_wo.p, d_wi.p, d_f.p, d_p.p);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(f3_out, d_f, 12 * (size_t)n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pdf_out, d_p, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_wo); (void)hipFree(d_wi); (void)hipFree(d_f); (void)hipFree(d_p);
+    HIP_TRY(hipMemcpy(f3_out, d_f.p, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf_out, d_p.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
     return AGPT_OK;
 }
 
@@ -859,24 +912,24 @@ int agpt_kat_bsdf_sample(agpt_scene* s, int material, int n, const float* wo3, c
         return fail(AGPT_ERR_INVALID, "agpt_kat_bsdf_sample: bad argument");
     agpt_ctx* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    float *d_wo, *d_u, *d_wi, *d_f, *d_p;
-    int32_t* d_s;
-    HIP_TRY(hipMalloc((void**)&d_wo, 12 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_u, 8 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_wi, 12 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_f, 12 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_p, 4 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_s, 4 * (size_t)n));
-    HIP_TRY(hipMemcpy(d_wo, wo3, 12 * (size_t)n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_u, u2, 8 * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat_bsdf_sample, dim3((n + 63) / 64), dim3(64), 0, c->stream, s->dev, material, n, d_wo, d_u, d_wi, d_f,
-                       d_p, d_s);
+    TempBuf<float> d_wo, d_u, d_wi, d_f, d_p;
+    TempBuf<int32_t> d_s;
+    HIP_TRY(d_wo.alloc(3 * (size_t)n));
+    HIP_TRY(d_u.alloc(2 * (size_t)n));
+    HIP_TRY(d_wi.alloc(3 * (size_t)n));
+    HIP_TRY(d_f.alloc(3 * (size_t)n));
+    HIP_TRY(d_p.alloc((size_t)n));
+    HIP_TRY(d_s.alloc((size_t)n));
+    HIP_TRY(hipMemcpy(d_wo.p, wo3, 12 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_u.p, u2, 8 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_bsdf_sample, dim3((n + 63) / 64), dim3(64), 0, c->stream, s->dev, material, n, d_wo.p, d_u.p, d_wi.p, d_f.p,
+                       d_p.p, d_s.p);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(wi3_out, d_wi, 12 * (size_t)n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(f3_out, d_f, 12 * (size_t)n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pdf_out, d_p, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(specular_out, d_s, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_wo); (void)hipFree(d_u); (void)hipFree(d_wi); (void)hipFree(d_f); (void)hipFree(d_p); (void)hipFree(d_s);
+    HIP_TRY(hipMemcpy(wi3_out, d_wi.p, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(f3_out, d_f.p, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf_out, d_p.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(specular_out, d_s.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
     return AGPT_OK;
 }
 
@@ -884,15 +937,196 @@ int agpt_kat_rng(agpt_ctx* c, uint32_t pixel, uint32_t wh, uint32_t sample, uint
                  uint32_t* seed_out) {
     if (!c || n <= 0 || !out || !seed_out) return fail(AGPT_ERR_INVALID, "agpt_kat_rng: bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    float* d_o;
-    uint32_t* d_s;
-    HIP_TRY(hipMalloc((void**)&d_o, 4 * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&d_s, 4));
-    hipLaunchKernelGGL(k_kat_rng, dim3(1), dim3(64), 0, c->stream, pixel, wh, sample, seed_base, n, d_o, d_s);
+    TempBuf<float> d_o;
+    TempBuf<uint32_t> d_s;
+    HIP_TRY(d_o.alloc((size_t)n));
+    HIP_TRY(d_s.alloc(1));
+    hipLaunchKernelGGL(k_kat_rng, dim3(1), dim3(64), 0, c->stream, pixel, wh, sample, seed_base, n, d_o.p, d_s.p);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, d_o, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(seed_out, d_s, 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_o); (void)hipFree(d_s);
+    HIP_TRY(hipMemcpy(out, d_o.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(seed_out, d_s.p, 4, hipMemcpyDeviceToHost));
+    return AGPT_OK;
+}
+
+
+// ---- multi-GPU: gather of the per-rank tile buffers ------------------------------------------------
+// RCCL is bound at run time (dlopen of the librccl already in the process, else the ROCm one): a single-GPU host never
+// loads it, and a host that also uses PyTorch shares PyTorch's copy instead of getting a second set of nccl* symbols.
+}  // extern "C"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi* rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.lib ? &api : nullptr;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) return nullptr;
+    bool ok = true;
+    auto sym = [&](const char* n) {
+        void* p = dlsym(api.lib, n);
+        ok = ok && p != nullptr;
+        return p;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) {
+        dlclose(api.lib);
+        api.lib = nullptr;
+        return nullptr;
+    }
+    return &api;
+}
+
+// compact rank buffer -> full accumulator.  Rank r owns the film's row blocks k with k % world == r; its j-th block sits at
+// compact rows [j*block, j*block + h) with the rows flipped inside the block (agpt_render's interleave layout), the full
+// accumulator is Accumulator::pixels: row (H-1-y) (myapp.h:17-19).  One thread per float4.
+__global__ void k_deinterleave(const float4* __restrict__ compact, float4* __restrict__ full, int W, int H, int block, int world,
+                               int rank, int rows_local) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows_local * (size_t)W) return;
+    const int row = (int)(i / (size_t)W), x = (int)(i - (size_t)row * (size_t)W);
+    const int j = row / block, r_in = row % block;
+    const int yb = (j * world + rank) * block;      // first film row of the block
+    const int hb = min(block, H - yb);
+    if (r_in >= hb) return;
+    const int y = yb + (hb - 1 - r_in);             // compact row j*block + (hb-1-within) holds film row yb + within
+    full[(size_t)(H - 1 - y) * (size_t)W + (size_t)x] = compact[i];
+}
+
+int rows_of_rank(int H, int block, int world, int rank) {
+    int rows = 0;
+    for (int k = rank, y = k * block; y < H; k += world, y = k * block) rows += std::min(block, H - y);
+    return rows;
+}
+
+}  // namespace
+
+struct agpt_comm {
+    agpt_ctx* ctx = nullptr;
+    int world = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    DevBuf<float4> staging;   // rank 0: one compact buffer per peer
+};
+
+extern "C" {
+
+int agpt_comm_unique_id(void* id128) {
+    if (!id128) return fail(AGPT_ERR_INVALID, "agpt_comm_unique_id: NULL argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    RcclApi* R = rccl();
+    if (!R) return fail(AGPT_ERR_DEVICE, "agpt_comm_unique_id: librccl.so could not be loaded");
+    ncclResult_t e = R->GetUniqueId((ncclUniqueId*)id128);
+    if (e != ncclSuccess) return fail(AGPT_ERR_DEVICE, std::string("ncclGetUniqueId: ") + R->GetErrorString(e));
+    return AGPT_OK;
+}
+
+int agpt_comm_init(agpt_ctx* c, const void* id128, int world, int rank, agpt_comm** out) {
+    if (!c || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128))
+        return fail(AGPT_ERR_INVALID, "agpt_comm_init: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::unique_ptr<agpt_comm> m(new agpt_comm());
+    m->ctx = c;
+    m->world = world;
+    m->rank = rank;
+    if (world > 1) {   // a single rank needs no communicator (and no RCCL)
+        RcclApi* R = rccl();
+        if (!R) return fail(AGPT_ERR_DEVICE, "agpt_comm_init: librccl.so could not be loaded");
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        ncclResult_t e = R->CommInitRank(&m->comm, world, id, rank);
+        if (e != ncclSuccess) return fail(AGPT_ERR_DEVICE, std::string("ncclCommInitRank: ") + R->GetErrorString(e));
+    }
+    *out = m.release();
+    return AGPT_OK;
+}
+
+void agpt_comm_destroy(agpt_comm* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->comm) (void)rccl()->CommDestroy(m->comm);
+    m->staging.release();
+    delete m;
+}
+
+int agpt_deinterleave_tiles(agpt_ctx* c, const float* compact_dev, int width, int height, int block_rows, int world, int rank,
+                            float* full_accum_dev) {
+    if (!c || !compact_dev || !full_accum_dev || width <= 0 || height <= 0 || block_rows <= 0 || world < 1 || rank < 0 || rank >= world)
+        return fail(AGPT_ERR_INVALID, "agpt_deinterleave_tiles: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int rows = rows_of_rank(height, block_rows, world, rank);
+    if (!rows) return AGPT_OK;
+    const size_t n = (size_t)rows * (size_t)width;
+    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float4*)compact_dev,
+                       (float4*)full_accum_dev, width, height, block_rows, world, rank, rows);
+    HIP_TRY(hipGetLastError());
+    return AGPT_OK;
+}
+
+int agpt_gather_tiles(agpt_comm* m, const float* local_accum_dev, int width, int height, int block_rows, float* full_accum_dev) {
+    if (!m || !local_accum_dev || width <= 0 || height <= 0 || block_rows <= 0 || (m->rank == 0 && !full_accum_dev))
+        return fail(AGPT_ERR_INVALID, "agpt_gather_tiles: bad argument");
+    agpt_ctx* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int world = m->world;
+    int max_rows = 0;
+    for (int r = 0; r < world; r++) max_rows = std::max(max_rows, rows_of_rank(height, block_rows, world, r));
+    const size_t slot = (size_t)max_rows * (size_t)width;   // float4 per rank buffer
+    if (world > 1) {
+        RcclApi* R = rccl();
+        ncclResult_t e = ncclSuccess;
+        if (m->rank == 0) {
+            int rc = m->staging.ensure(slot * (size_t)(world - 1));
+            if (rc) return rc;
+            // grouped point-to-point: every peer's buffer travels its own direct xGMI link to rank 0 (not a ring)
+            e = R->GroupStart();
+            for (int r = 1; r < world && e == ncclSuccess; r++) {
+                const size_t n = (size_t)rows_of_rank(height, block_rows, world, r) * (size_t)width * 4;
+                if (n) e = R->Recv(m->staging.p + slot * (size_t)(r - 1), n, ncclFloat, r, m->comm, c->stream);
+            }
+            if (e == ncclSuccess) e = R->GroupEnd();
+        } else {
+            const size_t n = (size_t)rows_of_rank(height, block_rows, world, m->rank) * (size_t)width * 4;
+            e = R->GroupStart();
+            if (e == ncclSuccess && n) e = R->Send(local_accum_dev, n, ncclFloat, 0, m->comm, c->stream);
+            if (e == ncclSuccess) e = R->GroupEnd();
+        }
+        if (e != ncclSuccess) return fail(AGPT_ERR_DEVICE, std::string("agpt_gather_tiles: ") + R->GetErrorString(e));
+    }
+    if (m->rank == 0) {
+        for (int r = 0; r < world; r++) {
+            const float* src = r == 0 ? local_accum_dev : (const float*)(m->staging.p + slot * (size_t)(r - 1));
+            int rc = agpt_deinterleave_tiles(c, src, width, height, block_rows, world, r, full_accum_dev);
+            if (rc) return rc;
+        }
+    }
     return AGPT_OK;
 }
 

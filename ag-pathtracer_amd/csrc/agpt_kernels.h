@@ -217,7 +217,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     constexpr bool MIS = MODE == 2;
     const int prim_base = CHUNKED ? 64 * chunk : 0;
     const bool carry = CHUNKED && chunk > 0;
-    __shared__ uint32_t s_stack[DEPTH * AGPT_BLOCK];
+    constexpr int BLOCK = AGPT_BLOCK;
+    __shared__ uint32_t s_stack[DEPTH * BLOCK];
     __shared__ float4 s_prim[2 * 64];
     uint32_t* stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -303,8 +304,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     r.fast = true;
 
     // wave-private ring of pre-filtered rays (path id + primitive mask), filled 64 rays at a time
-    __shared__ uint32_t s_ring_pid[AGPT_BLOCK / 64][AGPT_RING];
-    __shared__ unsigned long long s_ring_mask[AGPT_BLOCK / 64][AGPT_RING];
+    __shared__ uint32_t s_ring_pid[BLOCK / 64][AGPT_RING];
+    __shared__ unsigned long long s_ring_mask[BLOCK / 64][AGPT_RING];
     uint32_t* ring_pid = s_ring_pid[threadIdx.x >> 6];
     unsigned long long* ring_mask = s_ring_mask[threadIdx.x >> 6];
     uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, monotonically increasing
@@ -325,7 +326,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     uint32_t pfc_pid = 0, pfc_n = 0;   // stage C: the next chunk's rays (ray loads pending)
     bool pfc_valid = false;
     float4 pfc_o, pfc_d;
-    pfc_o.x = pfc_o.y = pfc_o.z = pfc_o.w = 0.f;
+    pfc_o.x = 0.f; pfc_o.y = 0.f; pfc_o.z = 0.f; pfc_o.w = 0.f;
     pfc_d = pfc_o;
     auto drained = [&]() -> bool { return segs_left == 0 && !pfa_valid && !pfb_valid && !pfc_valid; };
     auto pin_state = [&]() {   // see uni(): keeps the bookkeeping in scalar registers
@@ -557,7 +558,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     hr = hr && cur < rootpair_base;   // a root pair has no right child
                     if (hl && hr) {
                         bool swap = ANY ? false : (dr < dl);
-                        stack[sp * AGPT_BLOCK] = swap ? encl : encr;
+                        stack[sp * BLOCK] = swap ? encl : encr;
                         sp++;
                         cur = swap ? encr : encl;
                     } else if (hl) {
@@ -568,7 +569,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         cur = pick_next(mask);
                     } else {
                         sp--;
-                        cur = stack[sp * AGPT_BLOCK];
+                        cur = stack[sp * BLOCK];
                     }
                 }
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_balu += TCK_NOW() - tk_v1;)
@@ -580,21 +581,23 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     bool done = false;
                     for (uint32_t i = 0; i < cnt; ++i) {
                         const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
-                        float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        const v3 q0 = V3(a.x, a.y, a.z), q1 = V3(b.x, b.y, b.z), q2 = V3(c.x, c.y, c.z);
+                        const uint32_t q_id = __float_as_uint(a.w), q_flags = __float_as_uint(b.w);
                         float t, b1, b2;
                         if (COUNT) c_tri++;
-                        if (tri_test(V3(q0.x, q0.y, q0.z), V3(q1.x, q1.y, q1.z), V3(q2.x, q2.y, q2.z), r, rayt, t, b1, b2)) {
+                        if (tri_test(q0, q1, q2, r, rayt, t, b1, b2)) {
                             if (MIS) {
-                                if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
+                                if (!(q_flags & AGPT_TRI_FLAG_REJECT)) {
                                     done = true;
                                     break;
                                 }
                             } else if (ANY) {
                                 done = true;
                                 break;
-                            } else if (!(__float_as_uint(q1.w) & AGPT_TRI_FLAG_REJECT)) {
+                            } else if (!(q_flags & AGPT_TRI_FLAG_REJECT)) {
                                 rayt = t;
-                                hid = __float_as_uint(q0.w);
+                                hid = q_id;
                                 hb1 = b1;
                                 hb2 = b2;
                             }
@@ -607,7 +610,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         cur = pick_next(mask);
                     } else {
                         sp--;
-                        cur = stack[sp * AGPT_BLOCK];
+                        cur = stack[sp * BLOCK];
                     }
                 }
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_c += TCK_NOW() - tk_v1;)
@@ -1092,8 +1095,36 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 #ifndef AGPT_SHADE_WAVES
 #define AGPT_SHADE_WAVES 3
 #endif
+// LDS_TABLES: the scene's small tables -- Scene::primitives records, materials, lights -- are copied into LDS at kernel
+// start and every lookup of the shading code goes there.  As per-lane global loads they were ~50 separate load -> wait -> use
+// points inside one long dependent chain (their addresses depend on the hit), each paying an L1/L2 round trip with only
+// three waves per SIMD to cover it, and every store to the path state forced the compiler to re-load fields it already
+// had (it cannot prove that the tables and the path buffers do not alias).  Scenes whose tables exceed the limits below
+// use the global-memory instantiation.
+#define AGPT_SHADE_LDS_PRIMS 256
+#define AGPT_SHADE_LDS_MATERIALS 128
+#define AGPT_SHADE_LDS_LIGHTS 64
+template <bool LDS_TABLES>
 __global__ void __launch_bounds__(AGPT_BLOCK, AGPT_SHADE_WAVES)
-k_shade(DevScene sc, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout, DevCounters* __restrict__ counters) {
+k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout, DevCounters* __restrict__ counters) {
+    __shared__ DevPrim s_tab_prims[LDS_TABLES ? AGPT_SHADE_LDS_PRIMS : 1];
+    __shared__ DevMaterial s_tab_materials[LDS_TABLES ? AGPT_SHADE_LDS_MATERIALS : 1];
+    __shared__ DevLight s_tab_lights[LDS_TABLES ? AGPT_SHADE_LDS_LIGHTS : 1];
+    DevScene sc = sc_in;
+    if (LDS_TABLES) {
+        auto copy_words = [&](void* dst, const void* src, int n_bytes) {
+            uint32_t* d = (uint32_t*)dst;
+            const uint32_t* g = (const uint32_t*)src;
+            for (int i = threadIdx.x; i < n_bytes / 4; i += AGPT_BLOCK) d[i] = g[i];
+        };
+        copy_words(s_tab_prims, sc_in.prims, sc_in.n_prims * (int)sizeof(DevPrim));
+        copy_words(s_tab_materials, sc_in.materials, sc_in.n_materials * (int)sizeof(DevMaterial));
+        copy_words(s_tab_lights, sc_in.lights, sc_in.n_lights * (int)sizeof(DevLight));
+        sc.prims = s_tab_prims;
+        sc.materials = s_tab_materials;
+        sc.lights = s_tab_lights;
+        __syncthreads();
+    }
     __shared__ uint32_t s_pid[SHADE_U][AGPT_BLOCK];
     __shared__ uint32_t s_bits[SHADE_U][AGPT_BLOCK];
     __shared__ uint32_t s_cnt[4][SHADE_U * 4];

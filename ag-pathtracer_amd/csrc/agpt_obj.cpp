@@ -5,14 +5,23 @@
 // triangulate=true) and then:  transforms every `v` with mat4::TransformPoint (template/precomp.h:1020-1029), every
 // `vn` with TransformVector of Inverted().Transposed() (:208-217; skipped when ignore_normals), keeps `vt` as (u, v),
 // and concatenates the index triplets {vertex, normal, texcoord} of all shapes in order (:200-205) -- i.e. faces in file
-// order, one material for the whole mesh.  What is restated here from tinyobjloader is its published behaviour for the
-// statements a triangle mesh needs: `v`, `vn`, `vt`, `f` with v, v/vt, v//vn, v/vt/vn references, 1-based and negative
-// (relative) indices (fixIndex, tiny_obj_loader.h:770-790), faces with fewer than 3 corners dropped, and polygons
-// triangulated by its 2-D ear clipping (exportGroupsToShape, tiny_obj_loader.h:1376-1600: projection axes from the
-// first non-degenerate corner, signed area, pnpoly overlap test, fallback when no ear is found).  Everything else
-// (materials, groups, smoothing, lines, points, free-form geometry) does not influence LoadObj's output and is skipped.
-// PARITY UNPINNED: no OBJ fixture or reference output exists to pin this against (the reference cannot run here);
-// numbers are parsed with strtod and rounded to float, tinyobjloader uses its own decimal parser.
+// order, one material for the whole mesh.  Restated here from tinyobjloader, for the statements a triangle mesh needs:
+//   * its line reader (safeGetline, tiny_obj_loader.h:730-757: LF, CRLF and lone CR end a line) and statement dispatch
+//     (LoadObj, :2194-2745: leading blanks skipped, `v` / `vn` / `vt` / `f` / `l` / `p` / `g` / `o` need a blank after the keyword);
+//   * its own decimal parser tryParseDouble (:836-960) -- NOT strtod: digits accumulate in a double, the fraction through
+//     a power table / pow(10, -k), the exponent as ldexp(m * 5^e, e), parsing is greedy and a failed parse leaves the
+//     default (0, or 1 for w) -- then a cast to float;
+//   * index triples through atoi (parseTriple, :1093-1151) with 1-based and negative (relative to the counts at that
+//     line) indices (fixIndex, :765-787); a zero or unparsable index fails the whole load, also on `l` and `p` lines;
+//   * faces are kept per group and triangulated when the group is FLUSHED (`g`, `o`, end of file) against every vertex
+//     parsed up to then (exportGroupsToShape, :1365-1600): faces with fewer than 3 corners dropped, polygons cut by its
+//     2-D ear clipping (projection axes from the first non-degenerate corner, signed area, pnpoly overlap test, bail-out
+//     when no ear is found).
+// Materials do not reach LoadObj's output; `usemtl` (which flushes the open faces when the material id changes, :2465-2489)
+// is ignored, i.e. treated as tinyobjloader treats it when no .mtl file is found.  Pinned byte for byte against the
+// reference's own header by tests/golden/obj_cases.npz (oracle/ref_tinyobj.cpp, tests/golden/make_obj_golden.py).
+// Unlike the reference (which then indexes out of bounds), a face that references a vertex / normal / texcoord that does
+// not exist is an error here.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -102,31 +111,125 @@ bool fix_index(int idx, int n, int* ret) {
     return true;
 }
 
-// v, v/vt, v//vn, v/vt/vn
-bool parse_corner(const char*& p, int nv, int nvn, int nvt, Corner* c) {
-    c->v = c->vt = c->vn = -1;
-    char* e;
-    long iv = std::strtol(p, &e, 10);
-    if (e == p || !fix_index((int)iv, nv, &c->v)) return false;
-    p = e;
-    if (*p != '/') return true;
-    p++;
-    if (*p == '/') {  // v//vn
-        p++;
-        long in = std::strtol(p, &e, 10);
-        if (e == p || !fix_index((int)in, nvn, &c->vn)) return false;
-        p = e;
+// atoi as tinyobjloader uses it: optional blanks, optional sign, digits; anything else ends the number (0 if none)
+int c_atoi(const char* p) { return std::atoi(p); }
+
+// parseTriple (tiny_obj_loader.h:1093-1151): i, i/j/k, i//k, i/j
+bool parse_triple(const char*& token, int vsize, int vnsize, int vtsize, Corner* ret) {
+    Corner vi;
+    vi.v = vi.vt = vi.vn = -1;
+    if (!fix_index(c_atoi(token), vsize, &vi.v)) return false;
+    token += std::strcspn(token, "/ \t\r");
+    if (token[0] != '/') {
+        *ret = vi;
         return true;
     }
-    long it = std::strtol(p, &e, 10);
-    if (e == p || !fix_index((int)it, nvt, &c->vt)) return false;
-    p = e;
-    if (*p != '/') return true;
-    p++;
-    long in = std::strtol(p, &e, 10);
-    if (e == p || !fix_index((int)in, nvn, &c->vn)) return false;
-    p = e;
+    token++;
+    if (token[0] == '/') {   // i//k
+        token++;
+        if (!fix_index(c_atoi(token), vnsize, &vi.vn)) return false;
+        token += std::strcspn(token, "/ \t\r");
+        *ret = vi;
+        return true;
+    }
+    if (!fix_index(c_atoi(token), vtsize, &vi.vt)) return false;   // i/j/k or i/j
+    token += std::strcspn(token, "/ \t\r");
+    if (token[0] != '/') {
+        *ret = vi;
+        return true;
+    }
+    token++;   // i/j/k
+    if (!fix_index(c_atoi(token), vnsize, &vi.vn)) return false;
+    token += std::strcspn(token, "/ \t\r");
+    *ret = vi;
     return true;
+}
+
+inline bool is_digit(char x) { return static_cast<unsigned int>(x - '0') < 10u; }
+
+// tryParseDouble (tiny_obj_loader.h:836-960), operation for operation
+bool try_parse_double(const char* s, const char* s_end, double* result) {
+    if (s >= s_end) return false;
+    double mantissa = 0.0;
+    int exponent = 0;
+    char sign = '+', exp_sign = '+';
+    const char* curr = s;
+    int read = 0;
+    bool end_not_reached = false, leading_decimal_dots = false;
+    if (*curr == '+' || *curr == '-') {
+        sign = *curr;
+        curr++;
+        if ((curr != s_end) && (*curr == '.')) leading_decimal_dots = true;
+    } else if (is_digit(*curr)) {
+    } else if (*curr == '.') {
+        leading_decimal_dots = true;
+    } else {
+        return false;
+    }
+    end_not_reached = (curr != s_end);
+    if (!leading_decimal_dots) {
+        while (end_not_reached && is_digit(*curr)) {
+            mantissa *= 10;
+            mantissa += static_cast<int>(*curr - 0x30);
+            curr++;
+            read++;
+            end_not_reached = (curr != s_end);
+        }
+        if (read == 0) return false;
+    }
+    if (end_not_reached) {
+        bool has_exp = false;
+        if (*curr == '.') {
+            curr++;
+            read = 1;
+            end_not_reached = (curr != s_end);
+            while (end_not_reached && is_digit(*curr)) {
+                static const double pow_lut[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+                const int lut_entries = sizeof pow_lut / sizeof pow_lut[0];
+                mantissa += static_cast<int>(*curr - 0x30) * (read < lut_entries ? pow_lut[read] : std::pow(10.0, -read));
+                read++;
+                curr++;
+                end_not_reached = (curr != s_end);
+            }
+            has_exp = end_not_reached;
+        } else if (*curr == 'e' || *curr == 'E') {
+            has_exp = true;
+        }
+        if (has_exp && (*curr == 'e' || *curr == 'E')) {
+            curr++;
+            end_not_reached = (curr != s_end);
+            if (end_not_reached && (*curr == '+' || *curr == '-')) {
+                exp_sign = *curr;
+                curr++;
+            } else if (is_digit(*curr)) {   // (reads *s_end when the token ends in `e': a blank, CR or NUL -- never a digit)
+            } else {
+                return false;   // empty E is not allowed
+            }
+            read = 0;
+            end_not_reached = (curr != s_end);
+            while (end_not_reached && is_digit(*curr)) {
+                exponent *= 10;
+                exponent += static_cast<int>(*curr - 0x30);
+                curr++;
+                read++;
+                end_not_reached = (curr != s_end);
+            }
+            exponent *= (exp_sign == '+' ? 1 : -1);
+            if (read == 0) return false;
+        }
+    }
+    *result = (sign == '+' ? 1 : -1) * (exponent ? std::ldexp(mantissa * std::pow(5.0, exponent), exponent) : mantissa);
+    return true;
+}
+
+// parseReal (tiny_obj_loader.h:962-970)
+float parse_real(const char*& token, double default_value = 0.0) {
+    token += std::strspn(token, " \t");
+    const char* end = token + std::strcspn(token, " \t\r");
+    double val = default_value;
+    try_parse_double(token, end, &val);
+    token = end;
+    return static_cast<float>(val);
 }
 
 int pnpoly(int nvert, const float* vertx, const float* verty, float testx, float testy) {
@@ -254,52 +357,77 @@ int agpt_obj_parse(const char* text, size_t length, const float* transform16, in
     if (transform16) std::memcpy(M.c, transform16, sizeof(M.c));
     const Mat4 N = inverse_transpose(M);
     std::vector<float> v, vn, vt;
-    std::vector<Corner> corners;  // triangulated
-    std::string buf(text, length);
-    std::istringstream in(buf);
-    std::string line;
+    std::vector<Corner> corners;             // triangulated, all shapes concatenated (trianglemesh.cpp:200-205)
+    std::vector<std::vector<Corner>> group;  // PrimGroup::faceGroup: faces waiting for the next flush
+    auto flush = [&]() {                     // exportGroupsToShape for the open group
+        for (const std::vector<Corner>& face : group) triangulate(face, v, corners);
+        group.clear();
+    };
+    auto is_space = [](char x) { return x == ' ' || x == '\t'; };
+    auto is_new_line = [](char x) { return x == '\r' || x == '\n' || x == '\0'; };
     int lineno = 0;
-    while (std::getline(in, line)) {
+    size_t pos = 0;
+    std::string line;
+    while (pos < length) {   // safeGetline: LF, CRLF or a lone CR end a line
+        line.clear();
+        while (pos < length) {
+            const char ch = text[pos++];
+            if (ch == '\n') break;
+            if (ch == '\r') {
+                if (pos < length && text[pos] == '\n') pos++;
+                break;
+            }
+            line += ch;
+        }
         lineno++;
-        const char* p = line.c_str();
-        while (*p == ' ' || *p == '\t') p++;
-        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
-            char* e;
-            p += 2;
-            float x = (float)std::strtod(p, &e); p = e;
-            float y = (float)std::strtod(p, &e); p = e;
-            float z = (float)std::strtod(p, &e);
+        if (line.empty()) continue;
+        const char* token = line.c_str();
+        token += std::strspn(token, " \t");
+        if (token[0] == '\0' || token[0] == '#') continue;
+        if (token[0] == 'v' && is_space(token[1])) {   // parseVertexWithColor: x y z (+ optional colour, ignored by LoadObj)
+            token += 2;
+            const float x = parse_real(token), y = parse_real(token), z = parse_real(token);
             v.push_back(x); v.push_back(y); v.push_back(z);
-        } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
-            char* e;
-            p += 3;
-            float x = (float)std::strtod(p, &e); p = e;
-            float y = (float)std::strtod(p, &e); p = e;
-            float z = (float)std::strtod(p, &e);
+            continue;
+        }
+        if (token[0] == 'v' && token[1] == 'n' && is_space(token[2])) {
+            token += 3;
+            const float x = parse_real(token), y = parse_real(token), z = parse_real(token);
             vn.push_back(x); vn.push_back(y); vn.push_back(z);
-        } else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) {
-            char* e;
-            p += 3;
-            float x = (float)std::strtod(p, &e); p = e;
-            float y = (float)std::strtod(p, &e);
+            continue;
+        }
+        if (token[0] == 'v' && token[1] == 't' && is_space(token[2])) {
+            token += 3;
+            const float x = parse_real(token), y = parse_real(token);
             vt.push_back(x); vt.push_back(y);
-        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
-            p += 2;
+            continue;
+        }
+        const bool is_face = token[0] == 'f' && is_space(token[1]);
+        if (is_face || ((token[0] == 'l' || token[0] == 'p') && is_space(token[1]))) {
+            const char kind = token[0];
+            token += 2;
+            if (is_face) token += std::strspn(token, " \t");
             std::vector<Corner> face;
-            for (;;) {
-                while (*p == ' ' || *p == '\t') p++;
-                if (*p == '\0' || *p == '\r' || *p == '\n') break;
+            while (!is_new_line(token[0])) {
                 Corner c;
-                if (!parse_corner(p, (int)v.size() / 3, (int)vn.size() / 3, (int)vt.size() / 2, &c)) {
-                    g_obj_error = "agpt_obj_parse: failed to parse `f' line " + std::to_string(lineno) + " (zero or malformed index)";
+                if (!parse_triple(token, (int)v.size() / 3, (int)vn.size() / 3, (int)vt.size() / 2, &c)) {
+                    g_obj_error = std::string("agpt_obj_parse: failed to parse `") + kind + "' line " + std::to_string(lineno) +
+                                  " (zero or malformed index)";
                     return AGPT_ERR_INVALID;
                 }
                 face.push_back(c);
-                while (*p && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') p++;
+                token += std::strspn(token, " \t\r");
             }
-            triangulate(face, v, corners);
+            if (is_face) group.push_back(std::move(face));   // lines and points do not reach LoadObj's output
+            continue;
         }
+        if ((token[0] == 'g' || token[0] == 'o') && is_space(token[1])) {   // a new group / object flushes the open faces
+            flush();
+            continue;
+        }
+        // usemtl, mtllib, s, t, vw, free-form geometry: no influence on LoadObj's output (see the file comment for usemtl)
     }
+    flush();
     agpt_obj_mesh* m = new agpt_obj_mesh();
     m->vertices.resize(v.size());
     for (size_t i = 0; i + 2 < v.size(); i += 3) transform_point(M, &v[i], &m->vertices[i]);
@@ -316,9 +444,9 @@ int agpt_obj_parse(const char* text, size_t length, const float* transform16, in
             g_obj_error = "agpt_obj_parse: a face references a missing vertex / normal / texcoord (the reference would read out of bounds)";
             return AGPT_ERR_INVALID;
         }
-        m->indices.push_back(c.v);
-        m->indices.push_back(nn > 0 ? c.vn : c.v);
-        m->indices.push_back(nt > 0 ? c.vt : c.v);
+        m->indices.push_back(c.v);    // tinyobj's index_t as LoadObj copies it (trianglemesh.cpp:200-205): -1 = absent, which
+        m->indices.push_back(c.vn);   // only passes the check above when the mesh has no normals / texcoords at all
+        m->indices.push_back(c.vt);
     }
     if (m->indices.empty()) {
         delete m;

@@ -189,6 +189,26 @@ int agpt_intersect_device(agpt_scene*, const agpt_ray* rays_dev, int n, agpt_hit
  * has been enqueued and, if stats != NULL, synchronised. */
 int agpt_render(agpt_scene*, const agpt_render_params*, float* accum_dev, agpt_stats* stats);
 
+/* ---- multi-GPU (one process / context per GPU) -----------------------------------------------------------
+ * The reference is single-process (myapp.cpp:163-175 is its whole frame loop); a multi-GPU host splits the film into
+ * row blocks dealt round-robin to the ranks (agpt_render_params::interleave_*), every rank accumulates its blocks for
+ * the whole sample budget into its compact buffer, and ONE exchange at resolve time brings the buffers to rank 0.
+ * agpt_comm_unique_id: rank 0 fills a 128-byte id (ncclUniqueId) that the host passes to the other ranks by its own
+ * means (MPI_Bcast, a file, an environment variable); agpt_comm_init: every rank, collectively (world == 1 needs no id
+ * and never loads RCCL).  agpt_gather_tiles: every rank, collectively, enqueued on the context's stream -- grouped
+ * RCCL send/recv of the compact buffers to rank 0 (each peer over its own direct xGMI link) followed, on rank 0, by the
+ * de-interleave into the full accumulator full_accum_dev[height][width] float4 in Accumulator::pixels order (row
+ * H-1-y, myapp.h:17-19); full_accum_dev is ignored on the other ranks. */
+typedef struct agpt_comm agpt_comm;
+int agpt_comm_unique_id(void* id128);
+int agpt_comm_init(agpt_ctx*, const void* id128, int world, int rank, agpt_comm** out);
+void agpt_comm_destroy(agpt_comm*);
+int agpt_gather_tiles(agpt_comm*, const float* local_accum_dev, int width, int height, int block_rows, float* full_accum_dev);
+/* The de-interleave step alone (no communication; enqueued on the context's stream): writes the rows of `rank`'s compact
+ * buffer to their places in the full accumulator.  For hosts that move the buffers themselves (MPI, hipMemcpyPeer). */
+int agpt_deinterleave_tiles(agpt_ctx*, const float* compact_dev, int width, int height, int block_rows, int world, int rank,
+                            float* full_accum_dev);
+
 /* Accumulator::CopyToSurface (myapp.h:34-41): lin2rgb(sum/samples) -> 0x00RRGGBB.  accum_dev DEVICE float4,
  * out_rgb HOST uint32[w*h] */
 int agpt_resolve(agpt_ctx*, const float* accum_dev, int n_pixels, int samples, uint32_t* out_rgb);

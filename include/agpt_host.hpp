@@ -252,6 +252,7 @@ public:
     }
     int NumSamples() const { return samples_; }
     void AddSamples(int n) { samples_ += n; }
+    void SetSamples(int n) { samples_ = n; }
     float* device_pixels() const { return static_cast<float*>(pixels_); }
     // CopyToSurface: gamma 2.2 + 0x00RRGGBB (myapp.h:34-41)
     std::vector<uint32_t> CopyToSurface() const {
@@ -285,6 +286,34 @@ struct RankShare {
             if (k % world == rank) rows += (film_height - y0 < block_rows) ? film_height - y0 : block_rows;
         return rows;
     }
+};
+
+// The RCCL communicator of a multi-GPU render (one process and one Context per GPU).  Rank 0 obtains a 128-byte id with
+// Comm::UniqueId() and passes it to the other ranks by the host application's own means (MPI_Bcast, a file, ...); every rank
+// then constructs Comm(ctx, id, world, rank) collectively.  GatherTiles brings every rank's compact Accumulator to rank 0's
+// full-film Accumulator (agpt_gather_tiles: grouped send/recv over xGMI + de-interleave), once per displayed frame.
+class Comm {
+public:
+    static std::vector<unsigned char> UniqueId() {
+        std::vector<unsigned char> id(128);
+        check(agpt_comm_unique_id(id.data()), "agpt_comm_unique_id");
+        return id;
+    }
+    Comm(Context& ctx, const std::vector<unsigned char>& id, int world, int rank) {
+        check(agpt_comm_init(ctx.handle(), world > 1 ? id.data() : nullptr, world, rank, &h_), "agpt_comm_init");
+    }
+    ~Comm() { agpt_comm_destroy(h_); }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    // local: this rank's compact accumulator; full: the whole film on rank 0 (ignored, may be null, elsewhere)
+    void GatherTiles(const Accumulator& local, int film_height, const RankShare& share, Accumulator* full) {
+        check(agpt_gather_tiles(h_, local.device_pixels(), local.width, film_height, share.block_rows, full ? full->device_pixels() : nullptr),
+              "agpt_gather_tiles");
+        if (full) full->SetSamples(local.NumSamples());
+    }
+
+private:
+    agpt_comm* h_ = nullptr;
 };
 
 class PathTracer {

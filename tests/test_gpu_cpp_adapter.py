@@ -171,7 +171,16 @@ int main() {
             local += h;
         }
     }
-    std::printf("%s\n", std::memcmp(film.data(), ref.data(), film.size() * 4) == 0 ? "identical" : "DIFFERENT");
+    // the library's own gather (agpt_gather_tiles through agpt::Comm), world = 1: compact layout -> Accumulator::pixels order
+    Comm comm(ctx, {}, 1, 0);
+    RankShare one{8, 1, 0};
+    Accumulator compact(ctx, W, one.Rows(H)), gathered(ctx, W, H);
+    pt.Render(scene, compact, H, one, spp);
+    comm.GatherTiles(compact, H, one, &gathered);
+    std::vector<float> g = gathered.Download();
+    const bool ok = std::memcmp(film.data(), ref.data(), film.size() * 4) == 0 && std::memcmp(g.data(), ref.data(), g.size() * 4) == 0 &&
+                    gathered.NumSamples() == spp;
+    std::printf("%s\n", ok ? "identical" : "DIFFERENT");
     return 0;
 }''')
     exe = str(tmp_path / "shares")

@@ -93,3 +93,43 @@ def test_gloo_world2_gather_is_bit_identical(tmp_path, oracle):
     desc = ag.scenes.scene_c1(backdrop=oracle.create_backdrop([0, -1, 20], [40, 20, 40], 7.5, 32))
     ref, _ = desc.instantiate(oracle.OracleScene()).render(W, H, spp)
     assert got.tobytes() == ref.tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_gather_tiles_c_abi():
+    """agpt_gather_tiles / agpt_deinterleave_tiles (include/agpt.h): the compact per-rank buffers that agpt_render's row
+    interleave fills come back as the full Accumulator::pixels image.  One GPU: the three shares of a world-3 split are
+    rendered one after the other and de-interleaved by the library's kernel; the world-1 gather runs through
+    agpt_gather_tiles itself (no RCCL involved).  The RCCL send/recv path needs one GPU per rank and is NOT exercised here."""
+    import ag_pathtracer_amd as ag
+    from ag_pathtracer_amd import tiles
+    from helpers import gpu_context, gpu_scene
+    ctx = gpu_context()
+    scene = gpu_scene(ag.scenes.scene_c1())
+    pt = ag.PathTracer(5)
+    W, H, spp = 96, 77, 2          # 77 rows: the last 8-row block is short
+    ref, _ = pt.render_to_host(scene, W, H, spp)
+    full = ctx.alloc(W * H * 16)
+    try:
+        for world in (1, 3):
+            ctx.memset(full, 0xFF, W * H * 16)
+            for rank in range(world):
+                rows = tiles.max_local_rows(H, world)
+                local = ctx.alloc(rows * W * 16)
+                try:
+                    ctx.memset(local, 0, rows * W * 16)
+                    pt.render(scene, W, H, spp, local, accum_pitch=W, interleave=(tiles.BLOCK_ROWS, world, rank))
+                    if world == 1:
+                        comm = ag.Comm(ctx, 1, 0)
+                        comm.gather_tiles(local, W, H, tiles.BLOCK_ROWS, full)
+                        comm.close()
+                    else:
+                        ctx.deinterleave_tiles(local, W, H, tiles.BLOCK_ROWS, world, rank, full)
+                finally:
+                    ctx.download(local, (1,))   # synchronises the stream before the buffer is freed
+                    ctx.free(local)
+            got = ctx.download(full, (H, W, 4))
+            assert got[..., :3].tobytes() == ref[..., :3].tobytes(), "world %d" % world
+    finally:
+        ctx.free(full)
+        scene.close()
