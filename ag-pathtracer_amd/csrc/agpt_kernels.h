@@ -1089,7 +1089,9 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 // per-wave counts, one thread per queue scans them and reserves the tile's slots with ONE atomic, then every lane
 // writes its path id at its (order-preserving) offset -- 4 atomics per 1024 paths instead of 4 per wave: same-line
 // atomics serialise at ~11 ns each and were the kernel's bottleneck.
+#ifndef SHADE_U
 #define SHADE_U 4
+#endif
 // 3 waves/SIMD: the register allocator is capped at 168 VGPRs (48 spilled to scratch); measured 127 ms per C3 step
 // against 140 ms at 2 waves (217 VGPRs, no spills) and 151 ms at 4 waves (96 spilled).
 #ifndef AGPT_SHADE_WAVES
