@@ -13,6 +13,16 @@
 #include "agpt_host_scene.hpp"
 #include "agpt_kernels.h"
 
+// LDS stack entries of the production trace kernel (23 KiB of stack + 8 KiB = 31 KiB per block -> five blocks per CU) and the
+// blocks per CU that go with it; deeper BVHs spill the entries beyond into agpt_ctx::spill (HBM)
+#ifndef AGPT_FAST_STACK
+#define AGPT_FAST_STACK 23
+#endif
+#ifndef AGPT_FAST_BLOCKS_PER_CU
+#define AGPT_FAST_BLOCKS_PER_CU 5
+#endif
+
+
 namespace {
 
 thread_local std::string g_error;
@@ -74,7 +84,9 @@ struct agpt_ctx {
     DevBuf<uint32_t> work;      // work-queue heads of the persistent trace launches
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
-    int blocks_per_cu = 4;       // AGPT_BLOCKS_PER_CU
+    int blocks_per_cu = 4;       // generic trace kernel (32-entry LDS stacks)
+    int fast_blocks_per_cu = AGPT_FAST_BLOCKS_PER_CU;  // AGPT_BLOCKS_PER_CU: production trace kernel (AGPT_FAST_STACK-entry LDS stacks)
+    DevBuf<uint32_t> spill;      // traversal-stack entries beyond the LDS part (BVHs deeper than AGPT_FAST_STACK)
     int refill = AGPT_REFILL;    // AGPT_REFILL: idle lanes that trigger an in-flight refill (closest-hit launches)
     int refill_any = AGPT_REFILL_ANY;  // AGPT_REFILL_ANY: same for the any-hit / MIS-query launches
     bool mis_closest = false;    // AGPT_MIS_CLOSEST=1: trace MIS rays as full closest-hit queries (A/B, tests)
@@ -137,7 +149,8 @@ static int upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t st) {
     return AGPT_OK;
 }
 
-static int trace_grid(const agpt_ctx* c) { return c->num_cus * c->blocks_per_cu; }
+static int trace_grid(const agpt_ctx* c) { return c->num_cus * c->blocks_per_cu; }           // generic kernel
+static int fast_grid(const agpt_ctx* c) { return c->num_cus * c->fast_blocks_per_cu; }       // production kernel
 
 // count: 0 = off, 1 = reference-order counters (the generic kernel: what the reference's recursion does, equal to the
 // oracle's counters), 2 = the production kernel counting its own work (bench.py's roofline)
@@ -145,33 +158,46 @@ static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, int count) {
     return count != 1 && sc.n_prims <= 64 * AGPT_MAX_CHUNKS && !c->force_generic;
 }
 
-template <int MODE, int DEPTH, bool COUNT>
+// LDS stack entries of the production kernel (23 KiB of stack + 8 KiB = 31 KiB per block -> five blocks per CU) and the
+// blocks per CU that go with it; deeper BVHs spill the entries beyond into c->spill (HBM)
+template <int MODE, bool COUNT, bool SPILL>
 static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
                               uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, int refill) {
-    // 32-entry stacks: 40 KiB of LDS per block, four blocks per CU; 64-entry stacks (BVHs deeper than 32): two per CU
-    const dim3 block(AGPT_BLOCK), g(c->num_cus * (DEPTH <= AGPT_STACK_DEPTH ? c->blocks_per_cu : 2));
+    const dim3 block(AGPT_BLOCK), g(fast_grid(c));
     if (sc.n_prims <= 64) {
-        hipLaunchKernelGGL((k_trace_fast<MODE, DEPTH, false, COUNT>), g, block, 0, c->stream, sc, queue, count_ptr, count_imm,
-                           work_head, ro, rd, hits, occ, c->counters.p, refill, 0);
+        hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, COUNT, SPILL>), g, block, 0, c->stream, sc, queue, count_ptr,
+                           count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0, c->spill.p);
         return;
     }
     // more than 64 primitives: one launch per list-order chunk of 64 over the same queue
     const int chunks = (sc.n_prims + 63) / 64;
     for (int ch = 0; ch < chunks; ch++) {
         if (ch > 0) c->note(hipMemsetAsync(work_head, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL((k_trace_fast<MODE, DEPTH, true, COUNT>), g, block, 0, c->stream, sc, queue, count_ptr, count_imm,
-                           work_head, ro, rd, hits, occ, c->counters.p, refill, ch);
+        hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, true, COUNT, SPILL>), g, block, 0, c->stream, sc, queue, count_ptr,
+                           count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, ch, c->spill.p);
     }
 }
 
-template <int MODE, int DEPTH>
+template <int MODE>
 static void launch_trace_fast_c(agpt_ctx* c, int count, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr,
                                 uint32_t count_imm, uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits,
                                 uint32_t* occ, int refill) {
-    if (count)
-        launch_trace_fast<MODE, DEPTH, true>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
-    else
-        launch_trace_fast<MODE, DEPTH, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+    const bool spill = sc.max_depth > AGPT_FAST_STACK;
+    if (spill) {
+        // one column of (max_depth - AGPT_FAST_STACK) entries per thread of the grid
+        const size_t need = (size_t)(sc.max_depth - AGPT_FAST_STACK) * (size_t)fast_grid(c) * AGPT_BLOCK;
+        if (c->spill.ensure(need) != AGPT_OK) {
+            c->note(hipErrorOutOfMemory);
+            return;
+        }
+    }
+    if (count) {
+        if (spill) launch_trace_fast<MODE, true, true>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        else launch_trace_fast<MODE, true, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+    } else {
+        if (spill) launch_trace_fast<MODE, false, true>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        else launch_trace_fast<MODE, false, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+    }
 }
 
 // MODE 0 closest, 1 any-hit, 2 MIS query (production kernel only; the generic kernel traces MIS rays as closest hits)
@@ -182,10 +208,7 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
     dim3 grid(trace_grid(c)), block(AGPT_BLOCK);
     if (use_fast_trace(c, sc, count)) {
         const int refill = MODE == 0 ? c->refill : c->refill_any;
-        if (sc.max_depth <= AGPT_STACK_DEPTH)
-            launch_trace_fast_c<MODE, AGPT_STACK_DEPTH>(c, count, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
-        else
-            launch_trace_fast_c<MODE, AGPT_STACK_DEPTH_MAX>(c, count, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        launch_trace_fast_c<MODE>(c, count, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
     } else if (sc.max_depth > AGPT_STACK_DEPTH) {
         dim3 grid_deep(c->num_cus * 2);
         if (count)
@@ -247,7 +270,7 @@ int agpt_init(int device, agpt_ctx** out) {
     const char* fg = getenv("AGPT_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
     if (const char* mc = getenv("AGPT_MIS_CLOSEST")) c->mis_closest = mc[0] == '1';
-    if (const char* bp = getenv("AGPT_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(bp));
+    if (const char* bp = getenv("AGPT_BLOCKS_PER_CU")) c->fast_blocks_per_cu = std::max(1, atoi(bp));
     if (const char* rf = getenv("AGPT_REFILL")) c->refill = std::min(64, std::max(1, atoi(rf)));
     if (const char* rf = getenv("AGPT_REFILL_ANY")) c->refill_any = std::min(64, std::max(1, atoi(rf)));
     *out = c.release();
@@ -274,6 +297,7 @@ void agpt_destroy(agpt_ctx* c) {
     for (int i = 0; i < 2; i++)
         for (int j = 0; j < 4; j++) c->q[i][j].release();
     c->qcounts.release();
+    c->spill.release();
     c->work.release();
     c->counters.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);

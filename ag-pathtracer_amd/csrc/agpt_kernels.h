@@ -207,12 +207,20 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 // COUNT: the same kernel also counts the work it does -- child-pair records fetched (interior), root-pair records fetched
 // (roots: the mesh root-box tests that survive the prefilter) and triangle tests -- for bench.py's roofline; the counts
 // are per-lane sums, deterministic for a given queue (every lane's own operation sequence is fixed).
-template <int MODE, int DEPTH, bool CHUNKED, bool COUNT>
-__global__ void __launch_bounds__(AGPT_BLOCK)
+// DEPTH = per-lane stack entries kept in LDS.  SPILL: the scene's BVHs are deeper than that -- entries DEPTH and up live
+// in a per-thread column of an HBM buffer (spill[(k - DEPTH) * threads_in_grid + thread]); near-first descent rarely needs
+// them.  Occupancy is LDS-bound (DEPTH KiB of stack + 8 KiB per block): 23 entries -> 5 blocks = 20 waves per CU, which
+// is worth 9 % over the 4 blocks of a 32-entry stack (measured; the round-1 test of a fifth block used an exact 32-KiB fit
+// that never became resident).
+#ifndef AGPT_TRACE_WAVES
+#define AGPT_TRACE_WAVES 1   // minimum waves per SIMD the register allocation of k_trace_fast is held to
+#endif
+template <int MODE, int DEPTH, bool CHUNKED, bool COUNT, bool SPILL>
+__global__ void __launch_bounds__(AGPT_BLOCK, AGPT_TRACE_WAVES)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
              DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters, int refill,
-             int chunk) {
+             int chunk, uint32_t* __restrict__ spill) {
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
     const int prim_base = CHUNKED ? 64 * chunk : 0;
@@ -221,6 +229,18 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     __shared__ uint32_t s_stack[DEPTH * BLOCK];
     __shared__ float4 s_prim[2 * 64];
     uint32_t* stack = s_stack + threadIdx.x;
+    uint32_t* spill_col = SPILL ? spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
+    const size_t spill_stride = (size_t)gridDim.x * BLOCK;
+    auto stack_push = [&](int k, uint32_t v) {
+        if (!SPILL || k < DEPTH)
+            stack[k * BLOCK] = v;
+        else
+            spill_col[(size_t)(k - DEPTH) * spill_stride] = v;
+    };
+    auto stack_at = [&](int k) -> uint32_t {
+        if (!SPILL || k < DEPTH) return stack[k * BLOCK];
+        return spill_col[(size_t)(k - DEPTH) * spill_stride];
+    };
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // (a value loaded through a pointer counts as divergent for the compiler: readfirstlane keeps the bookkeeping scalar)
@@ -558,7 +578,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     hr = hr && cur < rootpair_base;   // a root pair has no right child
                     if (hl && hr) {
                         bool swap = ANY ? false : (dr < dl);
-                        stack[sp * BLOCK] = swap ? encl : encr;
+                        stack_push(sp, swap ? encl : encr);
                         sp++;
                         cur = swap ? encr : encl;
                     } else if (hl) {
@@ -569,7 +589,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         cur = pick_next(mask);
                     } else {
                         sp--;
-                        cur = stack[sp * BLOCK];
+                        cur = stack_at(sp);
                     }
                 }
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_balu += TCK_NOW() - tk_v1;)
@@ -610,7 +630,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         cur = pick_next(mask);
                     } else {
                         sp--;
-                        cur = stack[sp * BLOCK];
+                        cur = stack_at(sp);
                     }
                 }
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_c += TCK_NOW() - tk_v1;)
