@@ -30,10 +30,11 @@ import bench  # noqa: E402
 
 d, workload, out = sys.argv[1], sys.argv[2], sys.argv[3]
 def fam(k):
-    """kernel family of a dispatch; the COUNT instantiations of the counter pass (last template argument true) are not the
-    timed kernels and are left out"""
+    """kernel family of a dispatch; the COUNT instantiations of the counter pass (k_trace_fast<MODE, DEPTH, CHUNKED, COUNT, SPILL>
+    with COUNT = true) are not the timed kernels and are left out"""
     if "k_trace_fast<" in k:
-        return None if ", true>" in k.split("(")[0] else "trace"
+        args = [a.strip() for a in k.split("k_trace_fast<", 1)[1].split(">", 1)[0].split(",")]
+        return None if args[3] == "true" else "trace"
     return "shade" if k.startswith("k_shade") else None
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
