@@ -26,7 +26,7 @@ EXPORTS = [
     "agpt_scene_destroy", "agpt_scene_add_material", "agpt_scene_add_mesh", "agpt_scene_add_sphere",
     "agpt_scene_add_plane", "agpt_scene_add_area_light", "agpt_scene_add_uniform_infinite_light", "agpt_scene_add_infinite_area_light",
     "agpt_scene_set_camera",
-    "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_create_backdrop",
+    "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_toplevel_build", "agpt_create_backdrop",
     "agpt_intersect_batch", "agpt_intersect_device", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
     "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
@@ -113,6 +113,7 @@ def lib():
     L.agpt_mesh_num_prims.argtypes = [vp, C.c_int]
     L.agpt_mesh_get_bvh.argtypes = [vp, C.c_int, vp, ip]
     L.agpt_bvh_build.argtypes = [fp, C.c_int, ip, C.c_int, C.c_int, vp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.agpt_toplevel_build.argtypes = [fp, C.c_int, fp]
     L.agpt_create_backdrop.argtypes = [fp, fp, C.c_float, C.c_int, fp, fp, fp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.agpt_intersect_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.agpt_intersect_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Stats)]
@@ -175,6 +176,18 @@ def create_backdrop(origin, size, radius, steps):
                                       idx.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n_v), C.byref(n_i)),
            "agpt_create_backdrop")
     return verts, normals, uvs, idx
+
+
+def toplevel_build(boxes):
+    """agpt_toplevel_build: boxes[n, 6] (bmin, bmax) -> (lo[m, 3], hi[m, 3], skip[m], leaf[m]) with m = 2n - 1 nodes in depth-first
+    order; leaf[i] = index of the box at a leaf, -1 at an interior node; skip[i] = the node after i's subtree."""
+    boxes, pb = _f(np.asarray(boxes).reshape(-1, 6))
+    n = boxes.shape[0]
+    out = np.zeros((max(2 * n - 1, 1), 8), np.float32)
+    m = _check(lib().agpt_toplevel_build(pb, n, out.ctypes.data_as(C.POINTER(C.c_float))), "agpt_toplevel_build")
+    assert m == 2 * n - 1
+    words = out.view(np.uint32)
+    return out[:, 0:3].copy(), out[:, 4:7].copy(), words[:, 3].astype(np.int64), words[:, 7].astype(np.int32)
 
 
 def bvh_build(verts, indices, max_prims_in_node=1):

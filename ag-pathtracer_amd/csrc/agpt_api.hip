@@ -87,6 +87,9 @@ struct agpt_ctx {
     int blocks_per_cu = 4;       // generic trace kernel (32-entry LDS stacks)
     int fast_blocks_per_cu = AGPT_FAST_BLOCKS_PER_CU;  // AGPT_BLOCKS_PER_CU: production trace kernel (AGPT_FAST_STACK-entry LDS stacks)
     DevBuf<uint32_t> spill;      // traversal-stack entries beyond the LDS part (BVHs deeper than AGPT_FAST_STACK)
+    // primitive lists longer than 64 entries: per-path candidate words written by k_candidates, read by k_trace_fast<LIST>
+    DevBuf<unsigned long long> cand_mask;   // [chunk][pool_paths]
+    DevBuf<uint32_t> cand_chunks;           // [pool_paths]
     int refill = AGPT_REFILL;    // AGPT_REFILL: idle lanes that trigger an in-flight refill (closest-hit launches)
     int refill_any = AGPT_REFILL_ANY;  // AGPT_REFILL_ANY: same for the any-hit / MIS-query launches
     bool mis_closest = false;    // AGPT_MIS_CLOSEST=1: trace MIS rays as full closest-hit queries (A/B, tests)
@@ -120,7 +123,8 @@ struct agpt_scene {
     bool has_camera = false;
     bool committed = false;
     int max_depth = 0;
-    DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade, d_prefilter;
+    DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade, d_prefilter, d_toplevel;
+    DevBuf<unsigned long long> d_chunk_mesh_masks;
     DevBuf<uint32_t> d_bigleaves;
     DevBuf<DevPrim> d_prims;
     DevBuf<DevMaterial> d_materials;
@@ -166,16 +170,22 @@ static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* q
     const dim3 block(AGPT_BLOCK), g(fast_grid(c));
     if (sc.n_prims <= 64) {
         hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, COUNT, SPILL>), g, block, 0, c->stream, sc, queue, count_ptr,
-                           count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0, c->spill.p);
+                           count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0u, c->spill.p,
+                           (const unsigned long long*)nullptr, (const uint32_t*)nullptr);
         return;
     }
-    // more than 64 primitives: one launch per list-order chunk of 64 over the same queue
-    const int chunks = (sc.n_prims + 63) / 64;
-    for (int ch = 0; ch < chunks; ch++) {
-        if (ch > 0) c->note(hipMemsetAsync(work_head, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, true, COUNT, SPILL>), g, block, 0, c->stream, sc, queue, count_ptr,
-                           count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, ch, c->spill.p);
+    // more than 64 primitives: the top-level tree gives every ray its candidates (one word per chunk of 64 primitives), then
+    // ONE traversal launch walks them in list order
+    const uint32_t stride = (uint32_t)c->pool_paths;
+    if (c->cand_chunks.n < c->pool_paths || c->cand_mask.n < (size_t)((sc.n_prims + 63) / 64) * c->pool_paths) {
+        c->note(hipErrorOutOfMemory);   // (ensure_pool sizes both for the scene: not reached)
+        return;
     }
+    hipLaunchKernelGGL((k_candidates<MODE>), dim3(c->num_cus * 8), block, 0, c->stream, sc, queue, count_ptr, count_imm, ro, rd,
+                       c->cand_mask.p, c->cand_chunks.p, stride);
+    hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, true, COUNT, SPILL>), g, block, 0, c->stream, sc, queue, count_ptr,
+                       count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, stride, c->spill.p,
+                       (const unsigned long long*)c->cand_mask.p, (const uint32_t*)c->cand_chunks.p);
 }
 
 template <int MODE>
@@ -325,6 +335,8 @@ void agpt_scene_destroy(agpt_scene* s) {
     s->d_tri_verts.release();
     s->d_tri_shade.release();
     s->d_prefilter.release();
+    s->d_toplevel.release();
+    s->d_chunk_mesh_masks.release();
     s->d_prims.release();
     s->d_materials.release();
     s->d_lights.release();
@@ -494,6 +506,11 @@ int agpt_scene_commit(agpt_scene* s) {
     if ((rc = upload(s->d_tri_verts, flat.tri_verts, st))) return rc;
     if ((rc = upload(s->d_tri_shade, flat.tri_shade, st))) return rc;
     if ((rc = upload(s->d_prefilter, flat.prefilter, st))) return rc;
+    if ((rc = upload(s->d_toplevel, flat.toplevel, st))) return rc;
+    {
+        std::vector<unsigned long long> mm(flat.mesh_masks, flat.mesh_masks + AGPT_MAX_CHUNKS);
+        if ((rc = upload(s->d_chunk_mesh_masks, mm, st))) return rc;
+    }
     if ((rc = upload(s->d_prims, flat.prims, st))) return rc;
     if ((rc = upload(s->d_materials, s->materials, st))) return rc;
     if ((rc = upload(s->d_lights, lights, st))) return rc;
@@ -534,6 +551,9 @@ int agpt_scene_commit(agpt_scene* s) {
     for (int ch = 0; ch < AGPT_MAX_CHUNKS; ch++) s->dev.analytic_masks[ch] = flat.analytic_masks[ch];
     for (int ch = 0; ch <= AGPT_MAX_CHUNKS; ch++) s->dev.pf_begin[ch] = flat.pf_begin[ch];
     s->dev.prefilter = s->d_prefilter.p;
+    s->dev.toplevel = s->d_toplevel.p;
+    s->dev.n_toplevel = flat.n_toplevel;
+    s->dev.chunk_mesh_masks = s->d_chunk_mesh_masks.p;
     s->dev.n_meshes = 0;
     for (const DevPrim& dp : flat.prims)
         if (dp.type == AGPT_PRIM_MESH && dp.n_tris > 0) s->dev.n_meshes++;
@@ -578,6 +598,16 @@ int agpt_bvh_build(const float* vertices, int n_vertices, const int32_t* indices
     if (total_nodes_out) *total_nodes_out = m.total_nodes;
     if (max_depth_out) *max_depth_out = m.max_depth;
     return AGPT_OK;
+}
+
+int agpt_toplevel_build(const float* boxes6, int n, float* nodes8_out) {
+    if (!boxes6 || !nodes8_out || n < 1) return fail(AGPT_ERR_INVALID, "agpt_toplevel_build: need at least one box");
+    std::vector<uint32_t> payload((size_t)n);
+    for (int k = 0; k < n; k++) payload[k] = (uint32_t)k;
+    std::vector<float4> nodes;
+    agpt::build_skip_tree(boxes6, payload.data(), n, nodes);
+    std::memcpy(nodes8_out, nodes.data(), nodes.size() * sizeof(float4));
+    return (int)(nodes.size() / 2);
 }
 
 int agpt_create_backdrop(const float origin[3], const float size[3], float radius, int steps, float* vertices, float* normals,
@@ -644,10 +674,18 @@ static void release_pool(agpt_ctx* c) {
     c->mis_ok.release();
     for (int i = 0; i < 2; i++)
         for (int j = 0; j < 4; j++) c->q[i][j].release();
+    c->cand_mask.release();
+    c->cand_chunks.release();
     c->pool_paths = 0;
 }
-static int ensure_pool(agpt_ctx* c, size_t paths) {
+// extra pool bytes per path for a scene: the candidate words of lists longer than 64 primitives (k_candidates)
+static size_t candidate_bytes_per_path(int n_prims) { return n_prims > 64 ? 4 + 8 * (size_t)((n_prims + 63) / 64) : 0; }
+static int ensure_pool(agpt_ctx* c, size_t paths, int n_prims) {
     int rc;
+    if (n_prims > 64) {
+        if ((rc = c->cand_chunks.ensure(paths))) return rc;
+        if ((rc = c->cand_mask.ensure(paths * (size_t)((n_prims + 63) / 64)))) return rc;
+    }
     for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4,
                               &c->c1, &c->c2})
         if ((rc = b->ensure(paths))) return rc;
@@ -682,7 +720,7 @@ int agpt_intersect_device(agpt_scene* s, const agpt_ray* d_rays, int n, agpt_hit
     if (n == 0) return AGPT_OK;
     agpt_ctx* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_pool(c, (size_t)n);
+    int rc = ensure_pool(c, (size_t)n, s->dev.n_prims);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipMemsetAsync(c->work.p, 0, AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
@@ -766,16 +804,17 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     if ((size_t)NP * (size_t)S > c->pool_paths) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t avail = free_b + c->pool_paths * (size_t)AGPT_BYTES_PER_PATH;
-            const size_t fit = (size_t)((double)avail * 0.9) / (size_t)AGPT_BYTES_PER_PATH;
+            const size_t per_path = (size_t)AGPT_BYTES_PER_PATH + candidate_bytes_per_path(s->dev.n_prims);
+            const size_t avail = free_b + c->pool_paths * per_path;
+            const size_t fit = (size_t)((double)avail * 0.9) / per_path;
             while (S > 1 && (size_t)NP * (size_t)S > fit) S = (S + 1) / 2;
         }
     }
-    int rc = ensure_pool(c, (size_t)NP * S);
+    int rc = ensure_pool(c, (size_t)NP * S, s->dev.n_prims);
     while (rc == AGPT_ERR_NOMEM && S > 1) {
         release_pool(c);
         S = (S + 1) / 2;
-        rc = ensure_pool(c, (size_t)NP * S);
+        rc = ensure_pool(c, (size_t)NP * S, s->dev.n_prims);
     }
     if (rc) return rc;
     s->dev.cam = s->cam;

@@ -3,6 +3,7 @@
 #include "agpt_host_scene.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -365,6 +366,48 @@ static inline float bits(uint32_t u) {
     return f;
 }
 
+// Top-level structure over Scene::primitives (scene.h:5-19) for lists longer than 64 entries: ONE binary tree over the root
+// boxes of the non-empty meshes, laid out in depth-first order with skip links -- node i is two float4, (bmin.xyz, index of
+// the node that follows i's subtree) and (bmax.xyz, leaf: the primitive's list index / interior: ~0u) -- so a ray collects
+// its candidate meshes with a stackless walk: hit -> i + 1, miss -> skip.  The tree only selects CANDIDATES (a superset of
+// the meshes the reference's list walk can enter); the walk over them stays in list order.  Median split of the box
+// centres along their widest axis.
+static void toplevel_subtree(std::vector<float4>& nodes, std::vector<std::array<float, 7>>& e, size_t lo, size_t hi) {
+    float bmin[3] = {e[lo][0], e[lo][1], e[lo][2]}, bmax[3] = {e[lo][3], e[lo][4], e[lo][5]};
+    float cmin[3], cmax[3];
+    for (int a = 0; a < 3; a++) cmin[a] = cmax[a] = e[lo][a] + e[lo][3 + a];
+    for (size_t k = lo + 1; k < hi; k++)
+        for (int a = 0; a < 3; a++) {
+            bmin[a] = std::min(bmin[a], e[k][a]);
+            bmax[a] = std::max(bmax[a], e[k][3 + a]);
+            cmin[a] = std::min(cmin[a], e[k][a] + e[k][3 + a]);
+            cmax[a] = std::max(cmax[a], e[k][a] + e[k][3 + a]);
+        }
+    const size_t self = nodes.size() / 2;
+    nodes.push_back(F4(bmin[0], bmin[1], bmin[2], 0.f));
+    nodes.push_back(F4(bmax[0], bmax[1], bmax[2], hi - lo == 1 ? e[lo][6] : bits(0xFFFFFFFFu)));
+    if (hi - lo > 1) {
+        int axis = 0;
+        for (int a = 1; a < 3; a++)
+            if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+        const size_t mid = lo + (hi - lo) / 2;
+        std::nth_element(e.begin() + lo, e.begin() + mid, e.begin() + hi, [axis](const std::array<float, 7>& x, const std::array<float, 7>& y) {
+            return x[axis] + x[3 + axis] < y[axis] + y[3 + axis];
+        });
+        toplevel_subtree(nodes, e, lo, mid);
+        toplevel_subtree(nodes, e, mid, hi);
+    }
+    nodes[2 * self].w = bits((uint32_t)(nodes.size() / 2));
+}
+void build_skip_tree(const float* boxes6, const uint32_t* payload, int n, std::vector<float4>& nodes_out) {
+    std::vector<std::array<float, 7>> e((size_t)n);
+    for (int k = 0; k < n; k++) {
+        for (int a = 0; a < 6; a++) e[k][a] = boxes6[6 * k + a];
+        e[k][6] = bits(payload[k]);
+    }
+    if (n > 0) toplevel_subtree(nodes_out, e, 0, e.size());
+}
+
 void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSphere>& spheres,
                    const std::vector<HostPrim>& prims, FlatScene& out) {
     out.nodes.clear();
@@ -552,6 +595,22 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
     }
     out.pf_begin[AGPT_MAX_CHUNKS] = (int32_t)(out.prefilter.size() / 2);
     if (out.prefilter.empty()) out.prefilter.assign(2, F4(0, 0, 0, 0));
+    // top-level tree over the root boxes of all non-empty meshes (lists longer than 64 primitives, agpt_scene.h)
+    out.toplevel.clear();
+    if (out.prims.size() > 64) {
+        std::vector<float> boxes;
+        std::vector<uint32_t> index;
+        for (size_t pi = 0; pi < std::min<size_t>(out.prims.size(), 64 * (size_t)AGPT_MAX_CHUNKS); pi++) {
+            const DevPrim& dp = out.prims[pi];
+            if (dp.type == AGPT_PRIM_MESH && dp.n_tris > 0) {
+                boxes.insert(boxes.end(), {dp.root_bmin[0], dp.root_bmin[1], dp.root_bmin[2], dp.root_bmax[0], dp.root_bmax[1], dp.root_bmax[2]});
+                index.push_back((uint32_t)pi);
+            }
+        }
+        build_skip_tree(boxes.data(), index.data(), (int)index.size(), out.toplevel);
+    }
+    out.n_toplevel = (int32_t)(out.toplevel.size() / 2);
+    if (out.toplevel.empty()) out.toplevel.assign(2, F4(0, 0, 0, 0));
 }
 
 // ------------------------------------------------------------------------------------------------------------

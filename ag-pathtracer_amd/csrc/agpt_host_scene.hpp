@@ -73,7 +73,13 @@ struct FlatScene {
     // prefilter table (agpt_scene.h): two float4 per non-empty mesh in list order, chunk c = records [pf_begin[c], pf_begin[c+1])
     std::vector<float4> prefilter;
     int32_t pf_begin[AGPT_MAX_CHUNKS + 1] = {};
+    // top-level tree (agpt_scene.h), lists longer than 64 primitives only
+    std::vector<float4> toplevel;
+    int32_t n_toplevel = 0;
 };
+// one top-level tree (depth-first order, skip links) over n boxes (bmin.xyz, bmax.xyz each), appended to nodes_out;
+// payload[k] = the value stored in leaf k (the primitive's list index)
+void build_skip_tree(const float* boxes6, const uint32_t* payload, int n, std::vector<float4>& nodes_out);
 // per-mesh concatenation + per-triangle precomputation (trianglemesh.cpp:46-111's ray-independent part)
 void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSphere>& spheres,
                    const std::vector<HostPrim>& prims, FlatScene& out);

@@ -200,10 +200,11 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 // Every MIS ray is still traced through the BVH; it stops at the first blocker instead of finishing a closest-hit search.
 // DEPTH: per-lane stack entries in LDS -- AGPT_STACK_DEPTH (32 KiB/block, 4 blocks per CU) for the usual trees,
 // AGPT_STACK_DEPTH_MAX (64 KiB/block, 2 blocks per CU) for BVHs deeper than that
-// CHUNKED: scenes with more than 64 primitives are walked in list-order chunks of 64, one launch per chunk over the same
-// queue (the candidate mask is one 64-bit word).  chunk > 0 continues where the previous launch stopped: a closest-hit
-// ray starts from its hit record so far, an any-hit / MIS ray that is already decided is skipped, and only a blocker is
-// written -- exactly Scene::Intersect's sequential walk with a shared ray.t (scene.h:5-19).
+// LIST: scenes with more than 64 primitives.  k_candidates (below) has walked the top-level tree over the meshes' root
+// boxes once per ray and left one 64-bit candidate word per chunk of 64 primitives plus a word saying which chunks have
+// any (cand_mask[chunk * cand_stride + path], cand_chunks[path]); the lane walks its candidates chunk by chunk in list
+// order -- exactly Scene::Intersect's sequential walk with a shared ray.t (scene.h:5-19), minus the primitives the ray
+// cannot touch.  The prefilter and the LDS copy of the primitive records belong to the short-list instantiation only.
 // COUNT: the same kernel also counts the work it does -- child-pair records fetched (interior), root-pair records fetched
 // (roots: the mesh root-box tests that survive the prefilter) and triangle tests -- for bench.py's roofline; the counts
 // are per-lane sums, deterministic for a given queue (every lane's own operation sequence is fixed).
@@ -215,19 +216,18 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 #ifndef AGPT_TRACE_WAVES
 #define AGPT_TRACE_WAVES 1   // minimum waves per SIMD the register allocation of k_trace_fast is held to
 #endif
-template <int MODE, int DEPTH, bool CHUNKED, bool COUNT, bool SPILL>
+template <int MODE, int DEPTH, bool LIST, bool COUNT, bool SPILL>
 __global__ void __launch_bounds__(AGPT_BLOCK, AGPT_TRACE_WAVES)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
              DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters, int refill,
-             int chunk, uint32_t* __restrict__ spill) {
+             uint32_t cand_stride, uint32_t* __restrict__ spill, const unsigned long long* __restrict__ cand_mask,
+             const uint32_t* __restrict__ cand_chunks) {
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
-    const int prim_base = CHUNKED ? 64 * chunk : 0;
-    const bool carry = CHUNKED && chunk > 0;
     constexpr int BLOCK = AGPT_BLOCK;
     __shared__ uint32_t s_stack[DEPTH * BLOCK];
-    __shared__ float4 s_prim[2 * 64];
+    __shared__ float4 s_prim[LIST ? 2 : 2 * 64];
     uint32_t* stack = s_stack + threadIdx.x;
     uint32_t* spill_col = SPILL ? spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
     const size_t spill_stride = (size_t)gridDim.x * BLOCK;
@@ -245,9 +245,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // (a value loaded through a pointer counts as divergent for the compiler: readfirstlane keeps the bookkeeping scalar)
     const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)(count_ptr ? *count_ptr : count_imm));
-    const int n_prims = CHUNKED ? (sc.n_prims - prim_base < 64 ? sc.n_prims - prim_base : 64) : sc.n_prims;
+    const int n_prims = LIST ? 0 : sc.n_prims;   // (short lists: the primitive records live in LDS)
     if ((int)threadIdx.x < n_prims) {
-        const DevPrim& P = sc.prims[prim_base + threadIdx.x];
+        const DevPrim& P = sc.prims[threadIdx.x];
         float4 a, b;
         if (P.type == AGPT_PRIM_SPHERE) {
             a.x = P.cx; a.y = P.cy; a.z = P.cz; a.w = 1.f;
@@ -271,15 +271,21 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     // private ranges per wave instead measured 8 % slower (A/B on MI355X, same process).
     // A lane's scheduling state is carried by `cur` itself: CUR_IDLE = no ray, CUR_PICK = between meshes (state A),
     // anything below = an interior child-pair index (state B), sign bit set = a leaf encoding (state C).  One v_cmp per
-    // state gives the wave's vote masks.
-    constexpr uint32_t CUR_IDLE = 0x7FFFFFFFu, CUR_PICK = 0x7FFFFFFEu;
-    const uint32_t rootpair_base = sc.rootpair_base + 2u * (uint32_t)prim_base;
-    const unsigned long long mesh_mask = CHUNKED ? sc.mesh_masks[chunk] : sc.mesh_masks[0];
+    // state gives the wave's vote masks.  LIST adds CUR_FETCH (voted with state A): the current chunk's candidates are used
+    // up and the next chunk's word has to be fetched.
+    uint32_t pid = 0;
+    unsigned long long mask = 0;
+    constexpr uint32_t CUR_IDLE = 0x7FFFFFFFu, CUR_PICK = 0x7FFFFFFEu, CUR_FETCH = 0x7FFFFFFDu;
+    constexpr uint32_t CUR_B_END = LIST ? CUR_FETCH : CUR_PICK;   // state B: cur < CUR_B_END
+    const uint32_t rootpair_base = sc.rootpair_base;
+    const unsigned long long mesh_mask0 = sc.mesh_masks[0];
+    // LIST lane state: the mesh bits of the current chunk, and (current chunk << 16 | chunks still to visit, one bit each)
+    unsigned long long mmask = 0;
+    uint32_t cinfo = 0;
     // the sphere of an area light as (centre, r2), wherever it sits in the primitive list
     auto light_sphere = [&](int shape, v3& c, float& r2) {
-        const int ls = shape - prim_base;
-        if (!CHUNKED || (ls >= 0 && ls < n_prims)) {
-            const float4 sa = s_prim[2 * ls], sb = s_prim[2 * ls + 1];
+        if (!LIST) {
+            const float4 sa = s_prim[2 * shape], sb = s_prim[2 * shape + 1];
             c = V3(sa.x, sa.y, sa.z);
             r2 = sb.x;
         } else {
@@ -293,11 +299,25 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     // list go through state A.
     auto pick_next = [&](unsigned long long& m) -> uint32_t {
         const unsigned long long low = m & (0ull - m);
-        if (low & mesh_mask) {
+        if (LIST) {
+            if (m == 0) return (cinfo & 0xFFFFu) ? CUR_FETCH : CUR_PICK;
+            if (low & mmask) {
+                m ^= low;
+                return rootpair_base + 2u * (64u * (cinfo >> 16) + (uint32_t)(__ffsll((long long)low) - 1));
+            }
+            return CUR_PICK;
+        }
+        if (low & mesh_mask0) {
             m ^= low;
             return rootpair_base + 2u * (uint32_t)(__ffsll((long long)low) - 1);
         }
         return CUR_PICK;
+    };
+    // LIST: start on chunk c of the lane's ray (issues the loads of its candidate word and of the chunk's mesh bits)
+    auto enter_chunk = [&](uint32_t c) {
+        cinfo = (cinfo & 0xFFFFu & ~(1u << c)) | (c << 16);
+        mask = cand_mask[(size_t)c * cand_stride + pid];
+        mmask = sc.chunk_mesh_masks[c];
     };
     // Work distribution and the refill pipeline.  The queue is cut into AGPT_FRONTIERS contiguous segments, each with its own
     // frontier counter on its own 128-B line; a wave starts in the segment of its XCD (workgroups are dealt round-robin to
@@ -313,10 +333,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     // top-ups hide all of it; only a cold pipeline (kernel start, segment change) runs the chain synchronously.
     uint32_t seg = blockIdx.x & (AGPT_FRONTIERS - 1u), segs_left = AGPT_FRONTIERS;   // wave-uniform
     const uint32_t seg_len = ((count + AGPT_FRONTIERS - 1u) / AGPT_FRONTIERS + 63u) & ~63u;
-    uint32_t pid = 0, cur = CUR_IDLE, hid = AGPT_HIT_MISS;
+    uint32_t cur = CUR_IDLE, hid = AGPT_HIT_MISS;
     int sp = 0;
     float rayt = 0.f, hb1 = 0.f, hb2 = 0.f;
-    unsigned long long mask = 0;
     TraceRay r;
     r.O = V3s(0.f);
     r.D = V3(0.f, 0.f, 1.f);
@@ -356,14 +375,25 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     };
     auto pump_consume = [&]() {
         // stage C -> ring: conservative per-primitive prefilter of the 64 rays that arrived, all lanes busy
-        if (pfc_valid) {
+        if (LIST) {
+            // the candidates were collected by k_candidates: the ring carries the path id and its chunk word
+            if (pfc_valid) {
+                if ((uint32_t)lane < pfc_n) {
+                    const uint32_t slot = (ring_tail + (uint32_t)lane) & (AGPT_RING - 1);
+                    ring_pid[slot] = pfc_pid;
+                    ring_mask[slot] = (unsigned long long)__float_as_uint(pfc_o.x);
+                }
+                ring_tail += pfc_n;
+                pfc_valid = false;
+                TS(ts_pref++;)
+            }
+        } else if (pfc_valid) {
             if ((uint32_t)lane < pfc_n) {
                 const uint32_t npid = pfc_pid;
                 float4 o = pfc_o;
                 const float4 d = pfc_d;
                 const TraceRay nr = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                 unsigned long long skip_bit = 0;
-                bool decided = false;  // chunk > 0: nothing in this chunk can change the ray's answer any more
                 if (MIS) {   // MIS rays carry the sampled light's sphere (primitive index, ~0u = infinite light) in o.w; tmax = inf
                     const uint32_t shape = __float_as_uint(o.w);
                     o.w = AGPT_FLT_MAX;
@@ -372,15 +402,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         float lr2, ts;
                         light_sphere((int)shape, lc, lr2);
                         if (sphere_test_c(lc, lr2, nr, o.w, ts)) o.w = ts;
-                        const int ls = (int)shape - prim_base;
-                        if (!CHUNKED || (ls >= 0 && ls < 64)) skip_bit = 1ull << ls;
+                        skip_bit = 1ull << shape;
                     }
-                }
-                if (carry) {
-                    if (MODE == 0)
-                        o.w = hits[npid].t;
-                    else
-                        decided = MODE == 1 ? occluded[npid] != 0u : occluded[npid] == 0u;
                 }
                 // t ~ fma(b, R, -RN(O*R)) differs from the exact quotient (b-O)/D by at most 2^-23 |t| + 2^-24 |O*R|
                 // (R = RN(1/D), one rounding of O*R, one of the fma); rejecting only when tmax*(1+2e-6) + 2E < tmin with
@@ -396,7 +419,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                 typedef const float __attribute__((address_space(4))) ConstF;
                 typedef const DevPrim __attribute__((address_space(4))) ConstPrim;
                 ConstF* pf = (ConstF*)sc.prefilter;
-                const int j0 = sc.pf_begin[CHUNKED ? chunk : 0], j1 = sc.pf_begin[(CHUNKED ? chunk : 0) + 1];
+                const int j0 = sc.pf_begin[0], j1 = sc.pf_begin[1];
 #pragma unroll 4
                 for (int j = j0; j < j1; ++j) {   // non-empty meshes: conservative slab test of the root box
                     ConstF* q = pf + 8 * j;   // (bmin.xyz, bit index), (bmax.xyz, -)
@@ -408,8 +431,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     const bool h = !(__builtin_fmaf(tmax, 1.000002f, slack2) < tmin);
                     m |= (unsigned long long)(h ? 1u : 0u) << __float_as_uint(q[3]);
                 }
-                ConstPrim* pr = (ConstPrim*)(sc.prims + prim_base);
-                for (unsigned long long am = sc.analytic_masks[CHUNKED ? chunk : 0]; am; am &= am - 1) {   // spheres, planes: exact
+                ConstPrim* pr = (ConstPrim*)sc.prims;
+                for (unsigned long long am = sc.analytic_masks[0]; am; am &= am - 1) {   // spheres, planes: exact
                     const int k = __ffsll((long long)am) - 1;
                     ConstPrim& P = pr[k];
                     float root;
@@ -418,7 +441,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                 }
                 const uint32_t slot = (ring_tail + (uint32_t)lane) & (AGPT_RING - 1);
                 ring_pid[slot] = npid;
-                ring_mask[slot] = decided ? 0ull : ((nr.fast ? m : all_prims) & ~skip_bit);
+                ring_mask[slot] = (nr.fast ? m : all_prims) & ~skip_bit;
             }
             ring_tail += pfc_n;
             pfc_valid = false;
@@ -457,8 +480,12 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         if (adv_b) {   // B -> C: fetch the rays of the path ids that have arrived
             pfc_pid = b_pid;
             pfc_n = b_n;
-            pfc_o = ray_o[b_pid];
-            pfc_d = ray_d[b_pid];
+            if (LIST) {
+                pfc_o.x = __uint_as_float(cand_chunks[b_pid]);
+            } else {
+                pfc_o = ray_o[b_pid];
+                pfc_d = ray_d[b_pid];
+            }
             pfc_valid = true;
         }
         pfb_valid = false;
@@ -505,6 +532,12 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     const uint32_t slot = (ring_head + rank) & (AGPT_RING - 1);
                     pid = ring_pid[slot];
                     mask = ring_mask[slot];
+                    if (LIST) {   // the ring word says which chunks hold candidates: start on the first of them
+                        cinfo = (uint32_t)mask;
+                        mask = 0;
+                        mmask = 0;
+                        if (cinfo) enter_chunk((uint32_t)__ffs((int)cinfo) - 1u);
+                    }
                     float4 o = ray_o[pid], d = ray_d[pid];
                     r = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                     rayt = o.w;
@@ -519,7 +552,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                             float lr2, ts;
                             light_sphere((int)shape, lc, lr2);
                             mis_area = true;
-                            mis_skip = (int)shape - prim_base;   // position in this chunk's numbering (may lie outside it)
+                            mis_skip = (int)shape;
                             mis_reach = sphere_test_c(lc, lr2, r, rayt, ts);
                             if (mis_reach) rayt = ts;
                         }
@@ -527,13 +560,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     hid = AGPT_HIT_MISS;
                     hb1 = 0.f;
                     hb2 = 0.f;
-                    if (MODE == 0 && carry) {
-                        const DevHit ph = hits[pid];
-                        rayt = ph.t;
-                        hid = ph.id;
-                        hb1 = ph.b1;
-                        hb2 = ph.b2;
-                    }
                     sp = 0;
                     cur = pick_next(mask);
                 }
@@ -554,7 +580,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         // changes.  (A while-while loop makes every lane wait for the longest descent in the wave: 37 % active lanes.)
         for (;;) {
             TCK(const unsigned long long tk_v0 = TCK_NOW();)
-            const int nA = __popcll(__ballot(cur == CUR_PICK)), nB = __popcll(__ballot(cur < CUR_PICK)),
+            const int nA = __popcll(__ballot(LIST ? cur - CUR_FETCH < 2u : cur == CUR_PICK)), nB = __popcll(__ballot(cur < CUR_B_END)),
                       nC = __popcll(__ballot((int32_t)cur < 0));
             const int n_active = nA + nB + nC;
             if (n_active == 0 || (n_active <= 64 - refill && !(drained() && ring_head == ring_tail))) break;
@@ -562,7 +588,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             TS(ts_act += (unsigned long long)n_active; if (!(nB >= nA && nB >= nC) && !(nC >= nA)) { ts_steps[0]++; ts_lanes[0] += nA; })
             if (nB >= nA && nB >= nC) {
                 TS(ts_steps[1]++; ts_lanes[1] += nB;)
-                if (cur < CUR_PICK) {
+                if (cur < CUR_B_END) {
                     const NodePair np = load_pair(sc, cur);
                     TCK(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk_bmem += TCK_NOW() - tk_v1;)
                     float dl, dr;
@@ -634,13 +660,18 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                 }
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_c += TCK_NOW() - tk_v1;)
+            } else if (LIST && cur == CUR_FETCH) {
+                // the next chunk that holds candidates of this ray (one dependent load; list steps are rare)
+                enter_chunk((uint32_t)__ffs((int)(cinfo & 0xFFFFu)) - 1u);
+                cur = pick_next(mask);
+                TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_a += TCK_NOW() - tk_v1;)
             } else if (cur == CUR_PICK) {
                 // end of the primitive list (retire), or the sphere / plane that is next in list order
                 if (mask == 0) {
                     if (MIS) {
-                        if (!carry) occluded[pid] = mis_reach ? 1u : 0u;   // later chunks only ever write a blocker
+                        occluded[pid] = mis_reach ? 1u : 0u;
                     } else if (ANY) {
-                        if (!carry) occluded[pid] = 0u;
+                        occluded[pid] = 0u;
                     } else {
                         DevHit h;
                         h.t = rayt;
@@ -651,9 +682,18 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                     cur = CUR_IDLE;
                 } else {
-                    const int k = __ffsll((long long)mask) - 1;
+                    const int k = (LIST ? 64 * (int)(cinfo >> 16) : 0) + __ffsll((long long)mask) - 1;   // list index
                     mask &= mask - 1;
-                    const float4 pa = s_prim[2 * k], pb2 = s_prim[2 * k + 1];
+                    float4 pa, pb2;
+                    if (LIST) {   // (the short-list instantiation keeps these records in LDS)
+                        const DevPrim& P = sc.prims[k];
+                        const bool sphere = P.type == AGPT_PRIM_SPHERE;
+                        pa.x = P.cx; pa.y = P.cy; pa.z = P.cz; pa.w = sphere ? 1.f : (P.type == AGPT_PRIM_PLANE ? 3.f : 2.f);
+                        pb2.x = sphere ? P.r2 : P.r; pb2.y = sphere ? 0.f : P.r2; pb2.z = 0.f; pb2.w = 0.f;
+                    } else {
+                        pa = s_prim[2 * k];
+                        pb2 = s_prim[2 * k + 1];
+                    }
                     if (pa.w == 1.f || pa.w == 3.f) {
                         float root;
                         if (analytic_test(pa.w, V3(pa.x, pa.y, pa.z), pb2.x, pb2.y, r, rayt, root)) {
@@ -669,7 +709,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                                 cur = CUR_IDLE;
                             } else {
                                 rayt = root;
-                                hid = AGPT_HIT_SPHERE | (uint32_t)(prim_base + k);
+                                hid = AGPT_HIT_SPHERE | (uint32_t)k;
                                 hb1 = 0.f;
                                 hb2 = 0.f;
                             }
@@ -700,11 +740,105 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             atomicAdd(&counters->tris, (unsigned long long)c_tri);
         }
     }
-    if (threadIdx.x == 0 && blockIdx.x == 0 && !carry) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (MODE == 1)
             atomicAdd(&counters->anyhit_rays, (unsigned long long)count);
         else
             atomicAdd(&counters->closest_rays, (unsigned long long)count);   // MIS queries are Scene::Intersect calls
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Top-level structure over Scene::primitives (scene.h:5-19) for lists longer than 64 entries: one thread per ray walks the
+// tree over the meshes' root boxes (agpt_scene.h: depth-first order with skip links, so the walk needs no stack -- hit ->
+// next node, miss -> past the subtree) with the conservative slab test of the short-list prefilter, tests the spheres and
+// planes exactly, and leaves the ray's candidates as one 64-bit word per chunk of 64 primitives (cand_mask[chunk * stride +
+// path]) plus the set of non-empty chunks (cand_chunks[path]).  The candidates are a superset of the primitives the
+// reference's list walk can hit at the ray's initial t; k_trace_fast<LIST> visits them in list order and re-runs the exact
+// root-box test where the reference runs it.  No LDS besides the per-thread words and few registers: the dependent loads of
+// the walk are hidden by occupancy, which the traversal kernel (5 waves per SIMD) could not do (a per-lane tree walk inside
+// its prefilter measured 15 % slower than the per-primitive loop).
+static_assert(AGPT_MAX_CHUNKS <= 16, "k_trace_fast<LIST> keeps the chunks still to visit in 16 bits of a lane register");
+#define AGPT_CAND_LIST 24   // mesh candidates a thread of k_candidates collects before it gives up and marks every primitive
+template <int MODE>
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_candidates(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+             const float4* __restrict__ ray_o, const float4* __restrict__ ray_d, unsigned long long* __restrict__ cand_mask,
+             uint32_t* __restrict__ cand_chunks, uint32_t cand_stride) {
+    constexpr bool MIS = MODE == 2;
+    // the meshes the walk finds, as list indices, one column per thread (12 KiB per block: the register count, not LDS,
+    // bounds the occupancy); a ray with more than AGPT_CAND_LIST of them gets every primitive as candidate -- any superset
+    // of the true candidates is valid, the traversal re-tests each root box exactly
+    __shared__ uint16_t s_list[AGPT_CAND_LIST][AGPT_BLOCK];
+    const uint32_t count = count_ptr ? *count_ptr : count_imm;
+    const int n_chunks = (sc.n_prims + 63) / 64;
+    const int tid = threadIdx.x;
+    for (uint32_t i = blockIdx.x * AGPT_BLOCK + tid; i < count; i += gridDim.x * AGPT_BLOCK) {
+        const uint32_t pid = queue ? queue[i] : i;
+        float4 o = ray_o[pid];
+        const float4 d = ray_d[pid];
+        const TraceRay nr = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
+        uint32_t skip = 0xFFFFFFFFu;
+        if (MIS) {   // MIS rays carry the sampled light's sphere (primitive index, ~0u = infinite light) in o.w; tmax = inf
+            const uint32_t shape = __float_as_uint(o.w);
+            o.w = AGPT_FLT_MAX;
+            if (shape != 0xFFFFFFFFu) {
+                const DevPrim& L = sc.prims[shape];
+                float ts;
+                if (sphere_test_c(V3(L.cx, L.cy, L.cz), L.r2, nr, o.w, ts)) o.w = ts;
+                skip = shape;   // never a blocker itself
+            }
+        }
+        int n_found = 0;
+        bool all = !nr.fast;   // a direction component below 2^-40: the conservative form does not hold
+        if (!all) {
+            // same conservative form and slack as the short-list prefilter (k_trace_fast: pump_consume)
+            const float nox = -(nr.O.x * nr.R.x), noy = -(nr.O.y * nr.R.y), noz = -(nr.O.z * nr.R.z);
+            const float slack2 = 0x1p-21f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
+            uint32_t k = 0;
+            const uint32_t k_end = (uint32_t)sc.n_toplevel;
+            while (k < k_end) {
+                const float4 lo = sc.toplevel[2 * (size_t)k], hi = sc.toplevel[2 * (size_t)k + 1];
+                float t0x = __builtin_fmaf(lo.x, nr.R.x, nox), t1x = __builtin_fmaf(hi.x, nr.R.x, nox);
+                float t0y = __builtin_fmaf(lo.y, nr.R.y, noy), t1y = __builtin_fmaf(hi.y, nr.R.y, noy);
+                float t0z = __builtin_fmaf(lo.z, nr.R.z, noz), t1z = __builtin_fmaf(hi.z, nr.R.z, noz);
+                float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
+                float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), o.w));
+                const bool h = !(__builtin_fmaf(tmax, 1.000002f, slack2) < tmin);
+                const uint32_t prim = __float_as_uint(hi.w);
+                if (h && prim != 0xFFFFFFFFu) {
+                    if (n_found < AGPT_CAND_LIST) s_list[n_found][tid] = (uint16_t)prim;
+                    n_found++;
+                }
+                k = h ? k + 1u : __float_as_uint(lo.w);
+            }
+            all = n_found > AGPT_CAND_LIST;
+        }
+        uint32_t chunks = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            unsigned long long m;
+            if (all) {
+                const int n_here = sc.n_prims - 64 * c < 64 ? sc.n_prims - 64 * c : 64;
+                m = n_here >= 64 ? ~0ull : ((1ull << n_here) - 1ull);
+            } else {
+                m = 0;
+                for (int j = 0; j < n_found; ++j) {
+                    const uint32_t prim = s_list[j][tid];
+                    if ((int)(prim >> 6) == c) m |= 1ull << (prim & 63u);
+                }
+                for (unsigned long long am = sc.analytic_masks[c]; am; am &= am - 1) {   // spheres, planes: exact, as in the short-list prefilter
+                    const int b = __ffsll((long long)am) - 1;
+                    const DevPrim& P = sc.prims[64 * c + b];
+                    float root;
+                    const bool sphere = P.type == AGPT_PRIM_SPHERE;
+                    if (analytic_test(sphere ? 1.f : 3.f, V3(P.cx, P.cy, P.cz), sphere ? P.r2 : P.r, P.r2, nr, o.w, root)) m |= 1ull << b;
+                }
+            }
+            if (MIS && (int)(skip >> 6) == c) m &= ~(1ull << (skip & 63u));
+            cand_mask[(size_t)c * cand_stride + pid] = m;
+            chunks |= (m ? 1u : 0u) << c;
+        }
+        cand_chunks[pid] = chunks;
     }
 }
 

@@ -155,6 +155,12 @@ int agpt_mesh_get_bvh(const agpt_scene*, int prim, agpt_bvh_node* nodes_out, int
  * written, slot 1 unused); prim_index_out n_indices/3 entries.  Either output may be NULL. */
 int agpt_bvh_build(const float* vertices, int n_vertices, const int32_t* indices, int n_indices, int max_prims_in_node,
                    agpt_bvh_node* nodes_out, int32_t* prim_index_out, int* total_nodes_out, int* max_depth_out);
+/* The top-level structure the library builds over Scene::primitives (scene.h:5-19) when the list is longer than 64 entries,
+ * host-only (no GPU, no context): a binary tree over n boxes (6 floats each: bmin.xyz, bmax.xyz) in depth-first order with
+ * skip links.  Writes 2n-1 nodes of 8 floats -- (bmin.xyz, uint32 index of the node after this node's subtree), (bmax.xyz,
+ * uint32 leaf: index of the box / interior: 0xFFFFFFFF) -- and returns the node count.  A ray collects its candidate
+ * primitives with "hit -> next node, miss -> skip link"; the walk over the candidates stays in list order. */
+int agpt_toplevel_build(const float* boxes6, int n, float* nodes8_out);
 /* TriangleMesh::CreateBackdrop (trianglemesh.cpp:232-318), host-side scene prep.
  * capacities: vertices/normals 3*2*(steps+5) floats, texcoords 2*2*(steps+5), indices 3*6*(steps+4) ints */
 int agpt_create_backdrop(const float origin[3], const float size[3], float radius, int steps, float* vertices,

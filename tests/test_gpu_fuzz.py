@@ -53,7 +53,7 @@ def random_scene(seed):
         d.add_mesh(v, nn, t, idx, mats[rng.randint(len(mats))], int(rng.choice([1, 1, 2, 4])))
     for _ in range(rng.randint(0, 4) + (1 if n_mesh == 0 else 0)):
         d.add_sphere(rng.uniform(-2, 2, 3), float(rng.uniform(0.1, 1.2)), mats[rng.randint(len(mats))])
-    if rng.uniform() < 0.12:   # a long primitive list: the production kernel walks it in chunks of 64
+    if rng.uniform() < 0.12:   # a long primitive list: top-level tree + candidate words per chunk of 64
         for i in range(rng.randint(60, 150)):
             c = rng.uniform(-3, 3, 3)
             if rng.uniform() < 0.5:

@@ -95,8 +95,8 @@ def test_empty_and_invalid_inputs():
     g.close()
 
 
-def test_more_than_64_primitives_are_walked_in_chunks():
-    """> 64 primitives: the production kernel is launched once per list-order chunk of 64 (75 primitives = 2 chunks)."""
+def test_more_than_64_primitives_go_through_the_top_level_tree():
+    """> 64 primitives: k_candidates + k_trace_fast<LIST> (75 primitives = candidate words for 2 chunks of the list)."""
     rng = np.random.RandomState(5)
     d = ag.SceneDesc("many")
     m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
@@ -265,7 +265,7 @@ def test_device_pointer_entry_point_matches_host_entry_point():
 
 def test_render_with_200_primitives_lights_in_different_chunks():
     """Four chunks of the primitive list with meshes, spheres, two area lights (one in the first chunk, one in the last) and a
-    sky: closest-hit carry-over, any-hit and MIS queries across chunk boundaries, against the oracle."""
+    sky: closest hits, any-hit and MIS queries whose candidates span chunk boundaries, against the oracle."""
     from test_gpu_render import compare
     rng = np.random.RandomState(8)
     d = ag.SceneDesc("200-prims")

@@ -1,20 +1,21 @@
-"""Long primitive lists (Scene::primitives, scene.h:5-19): the production kernel walks up to 1024 primitives
-in list-order chunks of 64.  Parity = the hit records of the reference's linear walk (oracle), ties between primitives
-resolved in list order."""
+"""Long primitive lists (Scene::primitives, scene.h:5-19): for 65 ... 1024 primitives k_candidates walks a
+top-level tree over the meshes' root boxes and k_trace_fast<LIST> visits each ray's candidates in list order.  The tree only
+selects CANDIDATES, so parity = the hit records of the reference's linear walk (oracle), ties between primitives resolved in
+list order.  (The host-side tree builder is tested on the CPU in test_toplevel.py.)"""
 import numpy as np
 import pytest
 
 import ag_pathtracer_amd as ag
 
 
-def _many_prims(n_prims, seed, duplicates=True):
+def _many_prims(n_prims, seed, duplicates=True, sphere_every=9):
     rng = np.random.RandomState(seed)
     d = ag.SceneDesc("toplevel-%d" % n_prims)
     mats = [d.add_material(ag.MAT_DIFFUSE_ONLY, rng.uniform(.2, .9, 3)) for _ in range(3)]
     blobs = []
     for i in range(n_prims):
         c = rng.uniform(-6, 6, 3)
-        if i % 9 == 4:
+        if i % sphere_every == 4:
             d.add_sphere(c, float(rng.uniform(0.1, 0.4)), mats[i % 3])
         elif duplicates and i % 50 == 49 and blobs:
             # the same geometry again, hundreds of list positions (several chunks) later: every ray that hits it ties
@@ -29,8 +30,8 @@ def _many_prims(n_prims, seed, duplicates=True):
 
 @pytest.mark.gpu
 def test_gpu_900_primitives_hit_records_match_the_list_walk():
-    """15 chunks (lists beyond 512 used to fall back to the reference-order kernel): production kernel == instrumented
-    reference-order kernel == oracle, bit for bit, closest hit and any hit, with coincident meshes in different chunks."""
+    """Production kernel == instrumented reference-order kernel == oracle, bit for bit, closest hit and any hit, with
+    coincident meshes hundreds of list positions apart."""
     from test_gpu_intersect import check_closest, random_rays
     d = _many_prims(900, 21)
     assert d.n_prims == 900
@@ -48,3 +49,39 @@ def test_gpu_render_700_primitives_against_oracle():
     d.set_camera([0, 3, -16], [0, 0, 0], [0, 1, 0], 1.5, 50.0, 0.0)
     assert d.n_prims == 700
     compare(d, 64, 48, 2)
+
+
+@pytest.mark.gpu
+def test_gpu_ray_with_more_candidates_than_the_list_holds():
+    """120 meshes around the same spot: most rays cross far more than the 24 root boxes a k_candidates thread records; such a ray
+    gets every primitive as candidate (any superset is valid) and the answers stay those of the list walk."""
+    from test_gpu_intersect import check_closest, random_rays
+    rng = np.random.RandomState(3)
+    d = ag.SceneDesc("crowded")
+    m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
+    for i in range(120):
+        v, n, t, idx = ag.scenes.blob_mesh(5, 4, center=tuple(rng.uniform(-0.3, 0.3, 3)), radius=float(rng.uniform(0.5, 2.0)), seed=i)
+        d.add_mesh(v, n, t, idx, m, 1)
+    for i in range(6):
+        d.add_sphere(rng.uniform(-2, 2, 3), 0.3, m)
+    assert check_closest(d, random_rays(d, 40000, seed=9)) > 20000
+
+
+@pytest.mark.gpu
+def test_gpu_axis_parallel_rays_on_a_long_list():
+    """Direction components of exactly 0 (the reference relies on inf / NaN propagation in its slab test): the conservative form
+    of the candidate walk does not hold for them, they take every primitive as candidate."""
+    from test_gpu_intersect import check_closest
+    d = _many_prims(300, 41)
+    rng = np.random.RandomState(2)
+    n = 30000
+    rays = np.zeros(n, ag.RAY_DTYPE)
+    rays["o"] = rng.uniform(-7, 7, (n, 3)).astype(np.float32)
+    dirs = np.zeros((n, 3), np.float32)
+    axis = rng.randint(0, 3, n)
+    dirs[np.arange(n), axis] = rng.choice([-1.0, 1.0], n)
+    two = rng.uniform(size=n) < 0.5   # half of them lie in a coordinate plane instead of on an axis
+    dirs[two, (axis[two] + 1) % 3] = rng.normal(size=two.sum()).astype(np.float32)
+    rays["d"] = dirs
+    rays["tmax"] = np.float32(3.4e38)
+    assert check_closest(d, rays) > 1000
