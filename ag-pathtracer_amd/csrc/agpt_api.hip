@@ -892,6 +892,16 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         DevCounters dc;
         HIP_TRY(hipMemcpy(&dc, c->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
         read_counters(dc, stats);
+#ifdef AGPT_SHADE_CLOCK
+        {
+            const double tot = (double)dc.dbg[55];
+            static const char* names[8] = {"record loads", "resolve pending", "surface", "emission/termination", "BSDF set-up + light sampling",
+                                           "evaluations + ray stores", "final stores", "queue appends + barriers"};
+            std::fprintf(stderr, "[shade clock] wave-cycles %.4g:", tot);
+            for (int k = 0; k < 8; ++k) std::fprintf(stderr, "  %s %.1f%%", names[k], 100. * dc.dbg[56 + k] / tot);
+            std::fprintf(stderr, "\n");
+        }
+#endif
 #ifdef AGPT_TRACE_STATS
         for (int mode = 0; mode < 3; ++mode) {
             const unsigned long long* d = dc.dbg + 16 * mode;

@@ -79,8 +79,8 @@ __device__ __forceinline__ void pixel_of(const RenderConsts& rc, uint32_t p, int
 
 struct DevCounters {
     unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples, roots;
-#ifdef AGPT_TRACE_STATS
-    unsigned long long dbg[64];  // developer build only: wave-step statistics of k_trace_fast (tools/build_variant.py)
+#if defined(AGPT_TRACE_STATS) || defined(AGPT_SHADE_CLOCK)
+    unsigned long long dbg[64];  // developer builds only (tools/build_variant.py): wave-step statistics of k_trace_fast, phase clocks
 #endif
 };
 #ifdef AGPT_TRACE_STATS
@@ -940,7 +940,19 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
 #define SB_SHADOW 8u
 #define SB_SHADED 16u
 
-__device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderConsts& rc, const PathBuffers& pb, uint32_t pid) {
+// developer build -DAGPT_SHADE_CLOCK: s_memtime stamps at the phase boundaries of shade_path, summed over waves into
+// counters->dbg[56..63] (phase k ends at SCK(k); the stamp waits for outstanding memory so a phase owns its own latency)
+#ifdef AGPT_SHADE_CLOCK
+#define SCK_PARAMS , unsigned long long* sck_acc, unsigned long long& sck_last
+#define SCK_ARGS , sck_acc, sck_last
+#define SCK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long sck_now = __builtin_amdgcn_s_memtime(); \
+                    sck_acc[k] += sck_now - sck_last; sck_last = sck_now; } while (0)
+#else
+#define SCK_PARAMS
+#define SCK_ARGS
+#define SCK(k)
+#endif
+__device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderConsts& rc, const PathBuffers& pb, uint32_t pid SCK_PARAMS) {
     uint32_t bits = 0;
     // Every per-path record is fetched up front, unconditionally: the loads then overlap in one memory round trip instead
     // of forming a chain of dependent ones behind the flag tests (a record that turns out not to be needed is a coalesced
@@ -958,6 +970,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
     uint32_t flags = __float_as_uint(b4.w);
     uint32_t rng = __float_as_uint(l4.w);
 
+    SCK(0);   // records arrived
     // ---- resolve the previous vertex' UniformSampleOneLight (integrator.h:38-105) ------------------
     if (flags & PF_PENDING) {
         v3 Ld = V3s(0.f);
@@ -986,6 +999,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
         flags &= ~(PF_PENDING | PF_PEND_C1 | PF_PEND_C2);
     }
 
+    SCK(1);   // pending light sample resolved
     if (!(flags & PF_DEAD)) {
         uint32_t bounces = flags & PF_BOUNCE_MASK;
         v3 O = V3(o4.x, o4.y, o4.z), D = V3(d4.x, d4.y, d4.z);
@@ -997,6 +1011,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             else
                 surface_from_triangle(sc, h.id, h.b1, h.b2, O, D, h.t, s);
         }
+        SCK(2);   // surface record (tri_shade fetch + interpolation)
         // integrator.h:139-147
         if (bounces == 0 || (flags & PF_SPECULAR)) {
             if (found) {
@@ -1025,6 +1040,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             pb.ext_d[pid] = nd4;
             bits |= SB_EXT;
         } else {
+            SCK(3);   // emission, termination
             bits |= SB_SHADED;
             const DevMaterial& m = sc.materials[sc.prims[s.prim].material];
             Bsdf bsdf;
@@ -1091,6 +1107,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                 nee_visD = visD;
                 nee_visT = visT;
             }
+            SCK(4);   // BSDF set-up + light sampling
             // ---- the three BSDF evaluations of a vertex run through ONE loop with one evaluator call site:
             //   it 0: BSDF::f + BSDF::Pdf for the light sample          (integrator.h:46-47, reflection.h:114-123,174-188)
             //   it 1: EstimateDirect's BSDF-sampling leg, uScattering   (integrator.h:63-90,  BSDF::Sample_f reflection.h:124-172)
@@ -1224,6 +1241,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                     bits |= SB_EXT;
                 }
             }
+            SCK(5);   // the three evaluations incl. their ray / contribution stores
             if (flags & PF_PENDING) {  // the continuation factor and the chosen light wait for the resolve
                 float4 f4;
                 f4.x = fac.x; f4.y = fac.y; f4.z = fac.z; f4.w = __uint_as_float((uint32_t)numLight);
@@ -1236,6 +1254,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
     l4.x = L.x; l4.y = L.y; l4.z = L.z; l4.w = __uint_as_float(rng);
     pb.beta4[pid] = b4;
     pb.L4[pid] = l4;
+    SCK(6);   // final stores
     return bits;
 }
 
@@ -1245,6 +1264,9 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 // atomics serialise at ~11 ns each and were the kernel's bottleneck.
 #ifndef SHADE_U
 #define SHADE_U 4
+#endif
+#ifndef AGPT_SHADE_BLOCK_TILES
+#define AGPT_SHADE_BLOCK_TILES 0   // developer A/B: 1 = block-wide tiles of AGPT_BLOCK * SHADE_U entries with barriers (round-1 form)
 #endif
 // 3 waves/SIMD: the register allocator is capped at 168 VGPRs (48 spilled to scratch); measured 127 ms per C3 step
 // against 140 ms at 2 waves (217 VGPRs, no spills) and 151 ms at 4 waves (96 spilled).
@@ -1291,14 +1313,23 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t shaded = 0;
+#ifdef AGPT_SHADE_CLOCK
+    unsigned long long sck_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long sck_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long sck_begin = sck_last;
+#endif
+#if AGPT_SHADE_BLOCK_TILES
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 #pragma unroll 1
         for (int u = 0; u < SHADE_U; ++u) {
+#ifdef AGPT_SHADE_CLOCK
+            { const unsigned long long n0 = __builtin_amdgcn_s_memtime(); sck_acc[7] += n0 - sck_last; sck_last = n0; }   // queue appends, barriers
+#endif
             const uint32_t qi = tile * tile_size + (uint32_t)u * AGPT_BLOCK + (uint32_t)tid;
             uint32_t pid = 0, bits = 0;
             if (qi < n_active) {
                 pid = qin.active[qi];
-                bits = shade_path(sc, rc, pb, pid);
+                bits = shade_path(sc, rc, pb, pid SCK_ARGS);
             }
             s_pid[u][tid] = pid;
             s_bits[u][tid] = bits;
@@ -1337,6 +1368,59 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
         }
         __syncthreads();
     }
+#else
+    // Wave-private tiles of 64 * SHADE_U queue entries: the wave shades them, counts its appends per queue with ballots and
+    // reserves the slots with one atomic per queue (lanes 0..3, one queue each).  No block barrier: with block-wide tiles
+    // the three __syncthreads per tile made every wave wait for the slowest of its block -- 10 % of the kernel's wave
+    // time (s_memtime phase clocks) -- while 4x the atomics (one per queue per 256 paths) stay far below the ~11 ns per
+    // same-line atomic that had made per-wave-per-64-paths appends the bottleneck.
+    (void)n_tiles; (void)s_cnt; (void)s_off;
+    const uint32_t wtile = 64u * SHADE_U;
+    const uint32_t n_wtiles = (n_active + wtile - 1) / wtile;
+    for (uint32_t t = blockIdx.x * (AGPT_BLOCK / 64) + (uint32_t)wave; t < n_wtiles; t += gridDim.x * (AGPT_BLOCK / 64)) {
+        uint32_t total[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (int u = 0; u < SHADE_U; ++u) {
+#ifdef AGPT_SHADE_CLOCK
+            { const unsigned long long n0 = __builtin_amdgcn_s_memtime(); sck_acc[7] += n0 - sck_last; sck_last = n0; }   // queue appends
+#endif
+            const uint32_t qi = t * wtile + (uint32_t)u * 64u + (uint32_t)lane;
+            uint32_t pid = 0, bits = 0;
+            if (qi < n_active) {
+                pid = qin.active[qi];
+                bits = shade_path(sc, rc, pb, pid SCK_ARGS);
+            }
+            s_pid[u][tid] = pid;     // (slots private to the thread: no synchronisation)
+            s_bits[u][tid] = bits;
+            shaded += (bits & SB_SHADED) ? 1u : 0u;
+            for (int q = 0; q < 4; ++q) total[q] += (uint32_t)__popcll(__ballot((bits >> q) & 1u));
+        }
+        const uint32_t my_total = lane == 0 ? total[0] : (lane == 1 ? total[1] : (lane == 2 ? total[2] : total[3]));
+        uint32_t base = 0;
+        if (lane < 4 && my_total) base = atomicAdd(&QCOUNT(qout, lane), my_total);
+        uint32_t run[4];
+        for (int q = 0; q < 4; ++q) run[q] = (uint32_t)__shfl((int)base, q);
+        for (int u = 0; u < SHADE_U; ++u) {
+            const uint32_t bits = s_bits[u][tid];
+            const uint32_t pid = s_pid[u][tid];
+            for (int q = 0; q < 4; ++q) {
+                const bool pred = (bits >> q) & 1u;
+                const unsigned long long m = __ballot(pred);
+                if (pred) {
+                    uint32_t* qq = q == 0 ? qout.active : (q == 1 ? qout.ext : (q == 2 ? qout.mis : qout.shadow));
+                    qq[run[q] + (uint32_t)__popcll(m & lt_mask)] = pid;
+                }
+                run[q] += (uint32_t)__popcll(m);
+            }
+        }
+    }
+#endif
+#ifdef AGPT_SHADE_CLOCK
+    if (lane == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&counters->dbg[56 + k], sck_acc[k]);
+        atomicAdd(&counters->dbg[55], __builtin_amdgcn_s_memtime() - sck_begin);
+    }
+#endif
     // one atomic per wave, not per lane
     for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
     if (lane == 0 && shaded) atomicAdd(&counters->shaded, (unsigned long long)shaded);
