@@ -26,7 +26,7 @@ EXPORTS = [
     "agpt_scene_destroy", "agpt_scene_add_material", "agpt_scene_add_mesh", "agpt_scene_add_sphere",
     "agpt_scene_add_plane", "agpt_scene_add_area_light", "agpt_scene_add_uniform_infinite_light", "agpt_scene_add_infinite_area_light",
     "agpt_scene_set_camera",
-    "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_toplevel_build", "agpt_create_backdrop",
+    "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_toplevel_build", "agpt_toplevel_pack16", "agpt_create_backdrop",
     "agpt_intersect_batch", "agpt_intersect_device", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
     "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
@@ -114,6 +114,7 @@ def lib():
     L.agpt_mesh_get_bvh.argtypes = [vp, C.c_int, vp, ip]
     L.agpt_bvh_build.argtypes = [fp, C.c_int, ip, C.c_int, C.c_int, vp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.agpt_toplevel_build.argtypes = [fp, C.c_int, fp]
+    L.agpt_toplevel_pack16.argtypes = [fp, C.c_int, C.POINTER(C.c_uint32)]
     L.agpt_create_backdrop.argtypes = [fp, fp, C.c_float, C.c_int, fp, fp, fp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.agpt_intersect_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.agpt_intersect_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Stats)]
@@ -188,6 +189,24 @@ def toplevel_build(boxes):
     assert m == 2 * n - 1
     words = out.view(np.uint32)
     return out[:, 0:3].copy(), out[:, 4:7].copy(), words[:, 3].astype(np.int64), words[:, 7].astype(np.int32)
+
+
+def toplevel_pack16(lo, hi, skip, leaf):
+    """agpt_toplevel_pack16: the 16-byte node form of a tree from toplevel_build -> (lo16[m, 3], hi16[m, 3] as float16, skip[m], leaf[m])."""
+    m = len(skip)
+    nodes = np.zeros((m, 8), np.float32)
+    nodes[:, 0:3], nodes[:, 4:7] = lo, hi
+    w = nodes.view(np.uint32)
+    w[:, 3] = np.asarray(skip, np.uint32)
+    w[:, 7] = np.asarray(leaf, np.int64).astype(np.uint32)   # -1 -> 0xFFFFFFFF
+    packed = np.zeros((m, 4), np.uint32)
+    _check(lib().agpt_toplevel_pack16(nodes.ctypes.data_as(C.POINTER(C.c_float)), m, packed.ctypes.data_as(C.POINTER(C.c_uint32))),
+           "agpt_toplevel_pack16")
+    halves = np.stack([packed[:, 0] & 0xFFFF, packed[:, 0] >> 16, packed[:, 1] & 0xFFFF, packed[:, 1] >> 16, packed[:, 2] & 0xFFFF,
+                       packed[:, 2] >> 16], axis=1).astype(np.uint16).view(np.float16)
+    leaf16 = (packed[:, 3] >> 16).astype(np.int32)
+    leaf16[leaf16 == 0xFFFF] = -1
+    return halves[:, 0:3].copy(), halves[:, 3:6].copy(), (packed[:, 3] & 0xFFFF).astype(np.int64), leaf16
 
 
 def bvh_build(verts, indices, max_prims_in_node=1):

@@ -123,7 +123,8 @@ struct agpt_scene {
     bool has_camera = false;
     bool committed = false;
     int max_depth = 0;
-    DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade, d_prefilter, d_toplevel;
+    DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade, d_prefilter;
+    DevBuf<uint32_t> d_toplevel;
     DevBuf<unsigned long long> d_chunk_mesh_masks;
     DevBuf<uint32_t> d_bigleaves;
     DevBuf<DevPrim> d_prims;
@@ -506,7 +507,7 @@ int agpt_scene_commit(agpt_scene* s) {
     if ((rc = upload(s->d_tri_verts, flat.tri_verts, st))) return rc;
     if ((rc = upload(s->d_tri_shade, flat.tri_shade, st))) return rc;
     if ((rc = upload(s->d_prefilter, flat.prefilter, st))) return rc;
-    if ((rc = upload(s->d_toplevel, flat.toplevel, st))) return rc;
+    if ((rc = upload(s->d_toplevel, flat.toplevel16, st))) return rc;
     {
         std::vector<unsigned long long> mm(flat.mesh_masks, flat.mesh_masks + AGPT_MAX_CHUNKS);
         if ((rc = upload(s->d_chunk_mesh_masks, mm, st))) return rc;
@@ -551,7 +552,7 @@ int agpt_scene_commit(agpt_scene* s) {
     for (int ch = 0; ch < AGPT_MAX_CHUNKS; ch++) s->dev.analytic_masks[ch] = flat.analytic_masks[ch];
     for (int ch = 0; ch <= AGPT_MAX_CHUNKS; ch++) s->dev.pf_begin[ch] = flat.pf_begin[ch];
     s->dev.prefilter = s->d_prefilter.p;
-    s->dev.toplevel = s->d_toplevel.p;
+    s->dev.toplevel = reinterpret_cast<const uint4*>(s->d_toplevel.p);
     s->dev.n_toplevel = flat.n_toplevel;
     s->dev.chunk_mesh_masks = s->d_chunk_mesh_masks.p;
     s->dev.n_meshes = 0;
@@ -608,6 +609,16 @@ int agpt_toplevel_build(const float* boxes6, int n, float* nodes8_out) {
     agpt::build_skip_tree(boxes6, payload.data(), n, nodes);
     std::memcpy(nodes8_out, nodes.data(), nodes.size() * sizeof(float4));
     return (int)(nodes.size() / 2);
+}
+
+int agpt_toplevel_pack16(const float* nodes8, int n_nodes, uint32_t* packed4_out) {
+    if (!nodes8 || !packed4_out || n_nodes < 1) return fail(AGPT_ERR_INVALID, "agpt_toplevel_pack16: need at least one node");
+    std::vector<float4> nodes((size_t)2 * n_nodes);
+    std::memcpy(nodes.data(), nodes8, nodes.size() * sizeof(float4));
+    std::vector<uint32_t> packed;
+    agpt::pack_skip_tree16(nodes, packed);
+    std::memcpy(packed4_out, packed.data(), packed.size() * sizeof(uint32_t));
+    return n_nodes;
 }
 
 int agpt_create_backdrop(const float origin[3], const float size[3], float radius, int steps, float* vertices, float* normals,

@@ -399,6 +399,68 @@ static void toplevel_subtree(std::vector<float4>& nodes, std::vector<std::array<
     }
     nodes[2 * self].w = bits((uint32_t)(nodes.size() / 2));
 }
+// fp16 with directed rounding (k_candidates reads the tree as 16-byte nodes: boxes rounded OUTWARD to half precision stay
+// conservative).  Values below the smallest normal half (2^-14) go to 0 or +-2^-14, whichever is outward, so the result
+// does not depend on how the device treats half denormals; beyond +-65504 the outward value is +-inf.
+static float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
+    uint32_t f;
+    if (exp == 0) {
+        if (man == 0) f = sign;
+        else {   // denormal: man * 2^-24
+            float v = (float)man * 0x1p-24f;
+            std::memcpy(&f, &v, 4);
+            f |= sign;
+        }
+    } else if (exp == 31) f = sign | 0x7F800000u | (man << 13);
+    else f = sign | ((exp + 112u) << 23) | (man << 13);
+    float out;
+    std::memcpy(&out, &f, 4);
+    return out;
+}
+static uint16_t half_step(uint16_t h, bool up) {   // the neighbouring half in the given direction (h is not NaN)
+    const bool neg = (h & 0x8000u) != 0;
+    if ((h & 0x7FFFu) == 0) return up ? 0x0001u : 0x8001u;   // +-0 -> smallest denormal of the wanted sign
+    if (neg == up) return (uint16_t)(h - 1);                   // towards zero
+    return (h & 0x7FFFu) == 0x7C00u ? h : (uint16_t)(h + 1);  // away from zero, saturating at inf
+}
+static uint16_t half_outward(float v, bool up) {
+    if (v != v) return up ? 0x7C00u : 0xFC00u;
+    // start from a truncated conversion, then walk to the nearest half on the wanted side
+    uint32_t f;
+    std::memcpy(&f, &v, 4);
+    const uint32_t sign = (f >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((f >> 23) & 0xFFu) - 127;
+    uint16_t h;
+    if (e > 15) h = (uint16_t)(sign | 0x7C00u);
+    else if (e < -24) h = (uint16_t)sign;
+    else if (e < -14) h = (uint16_t)(sign | (((f & 0x7FFFFFu) | 0x800000u) >> (-e - 1)));
+    else h = (uint16_t)(sign | ((uint32_t)(e + 15) << 10) | ((f & 0x7FFFFFu) >> 13));
+    for (int guard = 0; guard < 4 && (up ? half_bits_to_float(h) < v : half_bits_to_float(h) > v); ++guard) h = half_step(h, up);
+    for (int guard = 0; guard < 4 && (up ? half_bits_to_float(half_step(h, !up)) >= v : half_bits_to_float(half_step(h, !up)) <= v) &&
+                        half_step(h, !up) != h; ++guard)
+        h = half_step(h, !up);   // (tighten: the truncated start may lie a step too far out)
+    if ((h & 0x7C00u) == 0 && (h & 0x3FFu) != 0) {   // a denormal: snap outward to 0 or +-2^-14
+        const bool neg = (h & 0x8000u) != 0;
+        h = (neg == up) ? (uint16_t)(neg ? 0x8000u : 0x0000u) : (uint16_t)((h & 0x8000u) | 0x0400u);
+    }
+    return h;
+}
+void pack_skip_tree16(const std::vector<float4>& nodes, std::vector<uint32_t>& packed) {
+    packed.clear();
+    for (size_t i = 0; 2 * i + 1 < nodes.size(); i++) {
+        const float4 &lo = nodes[2 * i], &hi = nodes[2 * i + 1];
+        uint32_t skip, leaf;
+        std::memcpy(&skip, &lo.w, 4);
+        std::memcpy(&leaf, &hi.w, 4);
+        const uint16_t lx = half_outward(lo.x, false), ly = half_outward(lo.y, false), lz = half_outward(lo.z, false);
+        const uint16_t hx = half_outward(hi.x, true), hy = half_outward(hi.y, true), hz = half_outward(hi.z, true);
+        packed.push_back((uint32_t)lx | ((uint32_t)ly << 16));
+        packed.push_back((uint32_t)lz | ((uint32_t)hx << 16));
+        packed.push_back((uint32_t)hy | ((uint32_t)hz << 16));
+        packed.push_back((skip & 0xFFFFu) | ((leaf == 0xFFFFFFFFu ? 0xFFFFu : (leaf & 0xFFFFu)) << 16));
+    }
+}
 void build_skip_tree(const float* boxes6, const uint32_t* payload, int n, std::vector<float4>& nodes_out) {
     std::vector<std::array<float, 7>> e((size_t)n);
     for (int k = 0; k < n; k++) {
@@ -610,7 +672,8 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
         build_skip_tree(boxes.data(), index.data(), (int)index.size(), out.toplevel);
     }
     out.n_toplevel = (int32_t)(out.toplevel.size() / 2);
-    if (out.toplevel.empty()) out.toplevel.assign(2, F4(0, 0, 0, 0));
+    pack_skip_tree16(out.toplevel, out.toplevel16);
+    if (out.toplevel16.empty()) out.toplevel16.assign(4, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -74,9 +74,13 @@ struct FlatScene {
     std::vector<float4> prefilter;
     int32_t pf_begin[AGPT_MAX_CHUNKS + 1] = {};
     // top-level tree (agpt_scene.h), lists longer than 64 primitives only
-    std::vector<float4> toplevel;
+    std::vector<float4> toplevel;       // builder output (fp32 boxes)
+    std::vector<uint32_t> toplevel16;   // the same tree as the device reads it: 4 words per node, boxes rounded outward to fp16
     int32_t n_toplevel = 0;
 };
+// 16-byte nodes from build_skip_tree's output: (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, skip | leaf << 16),
+// box coordinates as IEEE half rounded outward (lo down, hi up), skip / leaf as 16-bit indices (leaf 0xFFFF = interior)
+void pack_skip_tree16(const std::vector<float4>& nodes, std::vector<uint32_t>& packed);
 // one top-level tree (depth-first order, skip links) over n boxes (bmin.xyz, bmax.xyz each), appended to nodes_out;
 // payload[k] = the value stored in leaf k (the primitive's list index)
 void build_skip_tree(const float* boxes6, const uint32_t* payload, int n, std::vector<float4>& nodes_out);

@@ -798,19 +798,22 @@ k_candidates(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             uint32_t k = 0;
             const uint32_t k_end = (uint32_t)sc.n_toplevel;
             while (k < k_end) {
-                const float4 lo = sc.toplevel[2 * (size_t)k], hi = sc.toplevel[2 * (size_t)k + 1];
-                float t0x = __builtin_fmaf(lo.x, nr.R.x, nox), t1x = __builtin_fmaf(hi.x, nr.R.x, nox);
-                float t0y = __builtin_fmaf(lo.y, nr.R.y, noy), t1y = __builtin_fmaf(hi.y, nr.R.y, noy);
-                float t0z = __builtin_fmaf(lo.z, nr.R.z, noz), t1z = __builtin_fmaf(hi.z, nr.R.z, noz);
+                const uint4 nd = sc.toplevel[k];   // six halves (box rounded outward) + skip | leaf << 16
+                auto h2f = [](uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits16); };
+                const float lox = h2f(nd.x & 0xFFFFu), loy = h2f(nd.x >> 16), loz = h2f(nd.y & 0xFFFFu);
+                const float hix = h2f(nd.y >> 16), hiy = h2f(nd.z & 0xFFFFu), hiz = h2f(nd.z >> 16);
+                float t0x = __builtin_fmaf(lox, nr.R.x, nox), t1x = __builtin_fmaf(hix, nr.R.x, nox);
+                float t0y = __builtin_fmaf(loy, nr.R.y, noy), t1y = __builtin_fmaf(hiy, nr.R.y, noy);
+                float t0z = __builtin_fmaf(loz, nr.R.z, noz), t1z = __builtin_fmaf(hiz, nr.R.z, noz);
                 float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
                 float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), o.w));
                 const bool h = !(__builtin_fmaf(tmax, 1.000002f, slack2) < tmin);
-                const uint32_t prim = __float_as_uint(hi.w);
-                if (h && prim != 0xFFFFFFFFu) {
+                const uint32_t prim = nd.w >> 16;
+                if (h && prim != 0xFFFFu) {
                     if (n_found < AGPT_CAND_LIST) s_list[n_found][tid] = (uint16_t)prim;
                     n_found++;
                 }
-                k = h ? k + 1u : __float_as_uint(lo.w);
+                k = h ? k + 1u : (nd.w & 0xFFFFu);
             }
             all = n_found > AGPT_CAND_LIST;
         }

@@ -117,11 +117,14 @@ struct DevScene {
     // records [pf_begin[c], pf_begin[c + 1]).
     const float4* prefilter;
     int32_t pf_begin[AGPT_MAX_CHUNKS + 1];
-    // Top-level tree (primitive lists longer than 64 entries; agpt_host_scene.cpp: build_skip_tree): a binary tree over the root
-    // boxes of all non-empty meshes in depth-first order with skip links, node i = (bmin.xyz, index of the node after i's
-    // subtree), (bmax.xyz, leaf: list index of the primitive / interior: ~0u).  k_candidates walks it once per ray and leaves
-    // one 64-bit candidate word per chunk of 64 primitives; k_trace_fast<LIST> walks the candidates in list order.
-    const float4* toplevel;
+    // Top-level tree (primitive lists longer than 64 entries; agpt_host_scene.cpp: build_skip_tree, pack_skip_tree16): a binary
+    // tree over the root boxes of all non-empty meshes in depth-first order with skip links, one 16-byte node each: the box
+    // as six IEEE halves rounded OUTWARD (x: bmin.x | bmin.y << 16, y: bmin.z | bmax.x << 16, z: bmax.y | bmax.z << 16) and
+    // w: index of the node after this node's subtree | (leaf: list index of the primitive / interior: 0xFFFF) << 16.
+    // k_candidates walks it once per ray (one 16-byte load per visit: the walk is bound by the vector L1's rate for divergent
+    // loads) and leaves one 64-bit candidate word per chunk of 64 primitives; k_trace_fast<LIST> walks the candidates in
+    // list order and tests the exact fp32 root boxes.
+    const uint4* toplevel;   // 16-byte nodes, see below
     int32_t n_toplevel;
     const unsigned long long* chunk_mesh_masks;   // mesh_masks[] again, in global memory (per-lane chunk index)
     DevCamera cam;

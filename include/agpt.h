@@ -161,6 +161,10 @@ int agpt_bvh_build(const float* vertices, int n_vertices, const int32_t* indices
  * uint32 leaf: index of the box / interior: 0xFFFFFFFF) -- and returns the node count.  A ray collects its candidate
  * primitives with "hit -> next node, miss -> skip link"; the walk over the candidates stays in list order. */
 int agpt_toplevel_build(const float* boxes6, int n, float* nodes8_out);
+/* The 16-byte node form the GPU reads: per node 4 words -- bmin.x | bmin.y << 16, bmin.z | bmax.x << 16, bmax.y | bmax.z << 16
+ * as IEEE halves rounded OUTWARD (bmin down, bmax up; no half denormals; beyond +-65504 -> +-inf), skip | leaf << 16 as
+ * 16-bit indices (leaf 0xFFFF = interior).  nodes8 = agpt_toplevel_build's output.  Host-only. */
+int agpt_toplevel_pack16(const float* nodes8, int n_nodes, uint32_t* packed4_out);
 /* TriangleMesh::CreateBackdrop (trianglemesh.cpp:232-318), host-side scene prep.
  * capacities: vertices/normals 3*2*(steps+5) floats, texcoords 2*2*(steps+5), indices 3*6*(steps+4) ints */
 int agpt_create_backdrop(const float origin[3], const float size[3], float radius, int steps, float* vertices,

@@ -76,3 +76,33 @@ def test_skip_walk_finds_every_box_the_per_box_test_finds():
 def test_toplevel_build_rejects_bad_arguments():
     with pytest.raises(ag.AgptError):
         ag.toplevel_build(np.zeros((0, 6), np.float32))
+
+
+def test_pack16_rounds_boxes_outward():
+    """The GPU reads the tree as 16-byte nodes with half-precision boxes: every packed box must contain the fp32 one, be at most one
+    half step larger per coordinate, use no half denormals, and keep the links."""
+    rng = np.random.RandomState(7)
+    n = 300
+    boxes = _boxes(n, 11, flat=True)
+    # adversarial coordinates: tiny (below the smallest normal half), exactly representable, huge, zero and negative zero
+    boxes[0] = [-1e-7, 1e-7, -3e-6, 2e-7, 4e-6, 5e-6]
+    boxes[1] = [0.5, -0.25, 1024.0, 0.5, -0.25, 2048.0]
+    boxes[2] = [-7e4, -1e5, 6.5e4, 7e4, 1e5, 6.6e4]
+    boxes[3] = [0.0, -0.0, 0.0, 0.0, 0.0, -0.0]
+    boxes[4] = [-65504.0, 65504.0, -65505.0, -65504.0, 65505.0, 65504.0]
+    lo, hi, skip, leaf = ag.toplevel_build(boxes)
+    lo16, hi16, skip16, leaf16 = ag.toplevel_pack16(lo, hi, skip, leaf)
+    assert np.array_equal(skip16, skip) and np.array_equal(leaf16, leaf)
+    lo_f, hi_f = lo16.astype(np.float32), hi16.astype(np.float32)
+    assert np.all(lo_f <= lo) and np.all(hi_f >= hi)
+    for packed, exact, up in ((lo16, lo, False), (hi16, hi, True)):
+        bits = packed.view(np.uint16)
+        denormal = ((bits & 0x7C00) == 0) & ((bits & 0x03FF) != 0)
+        assert not denormal.any()
+        # tight: one step back towards the exact value would cross it (or the value is the denormal snap / an infinity)
+        with np.errstate(over="ignore"):
+            inward = np.nextafter(packed, np.float16(-np.inf) if up else np.float16(np.inf))
+        crosses = (inward.astype(np.float32) < exact) if up else (inward.astype(np.float32) > exact)
+        small = np.abs(exact) < 2.0 ** -14
+        assert np.all(crosses | small | np.isinf(packed.astype(np.float32)))
+    assert hi16[leaf == 2][0][0] == np.float16(np.inf) and lo16[leaf == 2][0][1] == np.float16(-np.inf)
