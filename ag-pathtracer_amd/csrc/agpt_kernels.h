@@ -6,11 +6,12 @@
 //     k_trace_fast<1>(shadow queue)  NEE shadow rays, any hit                           -> occluded[]
 //     k_shade(active queue)          resolves the previous vertex' NEE, then PathTracer::Li's loop body for the
 //                                    new hit; appends to the next iteration's queues with one atomic per queue per
-//                                    1024-path tile (ballot counts, order-preserving offsets)
-// (the instrumented / fallback k_trace traces MIS rays as closest hits into mis_hit[]).  The trace kernels are
+//                                    wave-private 256-path tile (ballot counts, order-preserving offsets)
+// (the instrumented / fallback k_trace traces MIS rays as closest hits into mis_hit[]).  Scenes with more than 64
+// primitives run k_candidates (top-level tree over Scene::primitives) in front of each trace launch.  The trace kernels are
 // persistent: a fixed grid of waves pulls 64-ray chunks off the queue; queue lengths stay on the device (no host round
 // trip per iteration).  Path state is SoA float4 in HBM (coalesced 16 B/lane); the per-lane traversal stack lives in LDS
-// (32 entries x 4 B x 256 lanes = 32 KiB/block).
+// (23 entries x 4 B x 256 lanes = 23 KiB/block, deeper entries in an HBM spill column).
 #pragma once
 
 #include "agpt_shade.h"

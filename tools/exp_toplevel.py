@@ -14,7 +14,10 @@ from test_gpu_long_lists import _many_prims
 
 def main():
     ctx = ag.Context(0)
-    for n_prims, sphere_every in ((64, 9), (200, 9), (500, 9), (1000, 9), (200, 100), (500, 100), (1000, 100)):
+    cases = ((64, 9), (200, 9), (500, 9), (1000, 9), (200, 100), (500, 100), (1000, 100))
+    if len(sys.argv) > 1:   # python tools/exp_toplevel.py 1000 [sphere_every]
+        cases = ((int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 100),)
+    for n_prims, sphere_every in cases:
         d = _many_prims(n_prims, 30 + n_prims, duplicates=False, sphere_every=sphere_every)
         scene = d.instantiate(ag.Scene(ctx))
         rng = np.random.RandomState(1)
