@@ -85,3 +85,42 @@ def test_gpu_axis_parallel_rays_on_a_long_list():
     rays["d"] = dirs
     rays["tmax"] = np.float32(3.4e38)
     assert check_closest(d, rays) > 1000
+
+
+@pytest.mark.gpu
+def test_gpu_long_list_render_is_split_invariant():
+    """300 primitives: the film is the same bit for bit whether it is rendered in one batch, in batches of one sample (the path
+    pool and the candidate words are re-used), with the production kernel counting its own work, or as three ranks' interleaved
+    row blocks reassembled -- and the work counters of the counting run are plausible."""
+    from helpers import gpu_scene
+    from ag_pathtracer_amd import tiles
+    d = _many_prims(297, 51)
+    d.add_area_light([0.0, 8.0, 0.0], 0.8, [70, 65, 60])
+    d.add_area_light([4.0, 7.0, -3.0], 0.5, [30, 40, 60])
+    d.add_plane([0, -6.5, 0], [10, 10], 0)
+    d.add_uniform_infinite_light([.25, .3, .35])
+    d.set_camera([0, 3, -16], [0, 0, 0], [0, 1, 0], 1.5, 50.0, 0.0)
+    assert d.n_prims == 300
+    W, H, spp = 96, 72, 3
+    g = gpu_scene(d)
+    pt = ag.PathTracer(5)
+    whole, st = pt.render_to_host(g, W, H, spp)
+    batched, _ = pt.render_to_host(g, W, H, spp, samples_per_batch=1)
+    counted, cst = pt.render_to_host(g, W, H, spp, counters=2)
+    assert whole.tobytes() == batched.tobytes() == counted.tobytes()
+    assert cst.rays == st.rays and cst.interior_visits > 5 * cst.closest_rays and cst.root_tests >= cst.closest_rays // 4
+    world = 3
+    rows_max = tiles.max_local_rows(H, world)
+    ctx = g.ctx
+    gathered = []
+    for rank in range(world):
+        local = ctx.alloc(rows_max * W * 16)
+        try:
+            ctx.memset(local, 0, rows_max * W * 16)
+            pt.render(g, W, H, spp, local, accum_pitch=W, interleave=(tiles.BLOCK_ROWS, world, rank))
+            gathered.append(ctx.download(local, (rows_max, W, 4)))
+        finally:
+            ctx.free(local)
+    full = tiles.deinterleave(gathered, W, H, world)
+    g.close()
+    assert np.array_equal(full.view(np.uint32), whole.view(np.uint32))
