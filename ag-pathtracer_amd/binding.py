@@ -50,7 +50,7 @@ class Stats(C.Structure):
                 ("tri_tests", C.c_uint64), ("shaded_vertices", C.c_uint64), ("samples", C.c_uint64),
                 ("outliers", C.c_uint64), ("iterations", C.c_uint64), ("trace_ms", C.c_double),
                 ("total_ms", C.c_double), ("trace_launches", C.c_uint64), ("root_tests", C.c_uint64),
-                ("ext_ms", C.c_double), ("mis_ms", C.c_double), ("shadow_ms", C.c_double)]
+                ("ext_ms", C.c_double), ("mis_ms", C.c_double), ("shadow_ms", C.c_double), ("answered_rays", C.c_uint64)]
 
     @property
     def rays(self):

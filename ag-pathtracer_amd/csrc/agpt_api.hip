@@ -723,6 +723,7 @@ static void read_counters(const DevCounters& d, agpt_stats* st) {
     st->shaded_vertices = d.shaded;
     st->outliers = d.outliers;
     st->samples = d.samples;
+    st->answered_rays = d.answered;
 }
 
 int agpt_intersect_device(agpt_scene* s, const agpt_ray* d_rays, int n, agpt_hit* d_out, int any_hit, agpt_stats* stats) {

@@ -79,7 +79,7 @@ __device__ __forceinline__ void pixel_of(const RenderConsts& rc, uint32_t p, int
 }
 
 struct DevCounters {
-    unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples, roots;
+    unsigned long long closest_rays, anyhit_rays, interior, tris, shaded, outliers, samples, roots, answered;
 #if defined(AGPT_TRACE_STATS) || defined(AGPT_SHADE_CLOCK)
     unsigned long long dbg[64];  // developer builds only (tools/build_variant.py): wave-step statistics of k_trace_fast, phase clocks
 #endif
@@ -943,6 +943,8 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
 #define SB_MIS 4u
 #define SB_SHADOW 8u
 #define SB_SHADED 16u
+#define SB_MIS_ANSWERED 32u   // a MIS query answered in k_shade (counted as the Scene::Intersect call it replaces, not enqueued)
+#define SB_RAY_ANSWERED 64u   // a continuation ray whose hit nothing reads (same bookkeeping)
 
 // developer build -DAGPT_SHADE_CLOCK: s_memtime stamps at the phase boundaries of shade_path, summed over waves into
 // counters->dbg[56..63] (phase k ends at SCK(k); the stamp waits for outstanding memory so a phase owns its own latency)
@@ -1214,6 +1216,24 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                             v3 c2 = isblack(Li2) ? V3s(0.f) : f * Li2 * weight / pdf;
                             v3 mO = s.p + AGPT_EPSILON * wi;
                             v3 mD = normalize(wi);
+                            // The query's answer for an area light is "the closest hit is the light's sphere" (integrator.h:82-85):
+                            // a ray that misses that sphere altogether cannot say yes, whatever else it meets, so it is answered
+                            // here -- by the very test the MIS-query kernel starts a ray with (k_trace_fast: mis_reach) -- and
+                            // never enters the queue.  BSDF-sampled directions rarely point at a small light: on C3 this
+                            // settles most of the queries of the two sphere lights.  (The ray still counts as the
+                            // Scene::Intersect call the reference makes.)
+                            bool reach = true;
+                            if (rc.mis_mode && light.type == AGPT_LIGHT_AREA) {
+                                const DevPrim& LS = sc.prims[light.shape];
+                                TraceRay qr;
+                                qr.O = mO;
+                                qr.D = mD;
+                                float ts;
+                                reach = sphere_test_c(V3(LS.cx, LS.cy, LS.cz), LS.r2, qr, AGPT_FLT_MAX, ts);
+                            }
+                            if (!reach) {
+                                bits |= SB_MIS_ANSWERED;
+                            } else {
                             float4 c4, mo4, md4;
                             c4.x = c2.x; c4.y = c2.y; c4.z = c2.z; c4.w = 0.f;
                             // tmax = FLT_MAX; the MIS-query kernel (mis_mode 1) is told the sampled light's sphere in its place
@@ -1226,6 +1246,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                             pb.mis_d[pid] = md4;
                             flags |= PF_PEND_C2;
                             bits |= SB_MIS;
+                            }
                         }
                     }
                 } else if (isblack(f) || pdf == 0) {   // integrator.h:175
@@ -1235,14 +1256,24 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                     if (!(flags & PF_PENDING)) beta = beta * fac;
                     flags = (flags & ~PF_SPECULAR) | (sampledSpecular ? PF_SPECULAR : 0u);
                     flags = (flags & ~PF_BOUNCE_MASK) | ((bounces + 1) & PF_BOUNCE_MASK);
-                    v3 nO = s.p + AGPT_EPSILON * wi;
-                    v3 nD = normalize(wi);
-                    float4 no4, nd4;
-                    no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
-                    nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
-                    pb.ext_o[pid] = no4;
-                    pb.ext_d[pid] = nd4;
-                    bits |= SB_EXT;
+                    if (rc.mis_mode && (int)(bounces + 1) >= rc.max_depth && !sampledSpecular) {
+                        // The ray that would follow ends the path whatever it hits: at the next vertex the loop adds emission
+                        // only after a specular bounce (integrator.h:139-147) and breaks on `bounces >= maxDepth` (:150) before
+                        // anything else looks at the intersection.  The reference still makes that Scene::Intersect call; its
+                        // answer cannot reach the image, so the production path counts the ray and does not trace it.  (The
+                        // path stays in the active queue for one more pass if this vertex' light sample is still pending.)
+                        flags |= PF_DEAD;
+                        bits |= SB_RAY_ANSWERED;
+                    } else {
+                        v3 nO = s.p + AGPT_EPSILON * wi;
+                        v3 nD = normalize(wi);
+                        float4 no4, nd4;
+                        no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
+                        nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
+                        pb.ext_o[pid] = no4;
+                        pb.ext_d[pid] = nd4;
+                        bits |= SB_EXT;
+                    }
                 }
             }
             SCK(5);   // the three evaluations incl. their ray / contribution stores
@@ -1316,7 +1347,7 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
     const uint32_t n_tiles = (n_active + tile_size - 1) / tile_size;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t shaded = 0;
+    uint32_t shaded = 0, mis_answered = 0;
 #ifdef AGPT_SHADE_CLOCK
     unsigned long long sck_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long sck_last = __builtin_amdgcn_s_memtime();
@@ -1338,6 +1369,7 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
             s_pid[u][tid] = pid;
             s_bits[u][tid] = bits;
             shaded += (bits & SB_SHADED) ? 1u : 0u;
+            mis_answered += ((bits & SB_MIS_ANSWERED) ? 1u : 0u) + ((bits & SB_RAY_ANSWERED) ? 1u : 0u);
         }
         for (int u = 0; u < SHADE_U; ++u) {
             const uint32_t bits = s_bits[u][tid];
@@ -1397,6 +1429,7 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
             s_pid[u][tid] = pid;     // (slots private to the thread: no synchronisation)
             s_bits[u][tid] = bits;
             shaded += (bits & SB_SHADED) ? 1u : 0u;
+            mis_answered += ((bits & SB_MIS_ANSWERED) ? 1u : 0u) + ((bits & SB_RAY_ANSWERED) ? 1u : 0u);
             for (int q = 0; q < 4; ++q) total[q] += (uint32_t)__popcll(__ballot((bits >> q) & 1u));
         }
         const uint32_t my_total = lane == 0 ? total[0] : (lane == 1 ? total[1] : (lane == 2 ? total[2] : total[3]));
@@ -1426,8 +1459,15 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
     }
 #endif
     // one atomic per wave, not per lane
-    for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
+    for (int off = 32; off > 0; off >>= 1) {
+        shaded += __shfl_down(shaded, off);
+        mis_answered += __shfl_down(mis_answered, off);
+    }
     if (lane == 0 && shaded) atomicAdd(&counters->shaded, (unsigned long long)shaded);
+    if (lane == 0 && mis_answered) {
+        atomicAdd(&counters->closest_rays, (unsigned long long)mis_answered);   // MIS queries are Scene::Intersect calls
+        atomicAdd(&counters->answered, (unsigned long long)mis_answered);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

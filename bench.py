@@ -272,7 +272,7 @@ def main():
             local.zero_()
             st = pt.render(scene, W, H, spp_, local.data_ptr(), accum_pitch=W, samples_per_batch=args.samples_per_batch,
                            timing=timing, interleave=interleave)
-            tot = dict(closest=st.closest_rays, anyhit=st.anyhit_rays, trace_ms=st.trace_ms, ext_ms=st.ext_ms, mis_ms=st.mis_ms,
+            tot = dict(closest=st.closest_rays, anyhit=st.anyhit_rays, answered=st.answered_rays, trace_ms=st.trace_ms, ext_ms=st.ext_ms, mis_ms=st.mis_ms,
                        shadow_ms=st.shadow_ms, total_ms=st.total_ms, launches=st.trace_launches, iterations=st.iterations)
             full = tiles.gather_to_rank0(local, W, H, rank, world, out_bufs=gather_bufs) if gather else None
             return tot, full
@@ -334,6 +334,11 @@ def main():
                 "triangles": desc.n_tris, "resolution": [W, H], "spp": spp,
                 "sharding": "8-row blocks round-robin, one RCCL gather to rank 0 per step" if world > 1 else "single GPU",
                 "rays_per_step": int(rays_total / args.steps), "rays_per_sample": round(rays_total / args.steps / (W * H * spp), 2),
+                # rays = the reference algorithm's ray queries (Scene::Intersect / IntersectP calls, equal to the CPU oracle's
+                # count); this many of them per step (rank 0's share) are settled exactly without a traversal: MIS queries towards
+                # a sphere light whose ray misses the light's sphere, and the ray after a path's last bounce whose hit nothing reads
+                "rays_answered_without_traversal_per_step": int(sums["answered"] / args.steps),
+                "traversed_mrays_s": round((rays_total - sums["answered"] * (rays_total / max(rays_local, 1.0))) / dt_max / 1e6, 2),
                 "msamples_per_s": round(W * H * spp * args.steps / dt_max / 1e6, 2),
             },
             "roofline": roofline_block(sums, cst, rays_local, args.steps, wl_key),
@@ -352,6 +357,8 @@ def main():
                         "%dx%d, %d spp (one GPU's film; the config's 4K / 1024 spp budget is that of 8 GPUs)"
                         % (desc5.n_tris, desc5.n_prims, W, H, spp),
             "value": round(rays5 / dt5 / 1e6, 2), "unit": "Mrays/s", "steps": 2, "warmup": 1, "ms_per_step": round(dt5 / 2 * 1e3, 2),
+            "rays_answered_without_traversal_per_step": int(sums5["answered"] / 2),
+            "traversed_mrays_s": round((rays5 - sums5["answered"]) / dt5 / 1e6, 2),
             "roofline": roofline_block(sums5, cst5, rays5, 2, "c5:%dx%d:%dspp:world1:scale1" % (W, H, spp)),
         }
         scene5.close()

@@ -84,6 +84,10 @@ typedef struct {
     uint64_t root_tests;      /* mesh root-box tests, bvhtrimesh.h:187,195 (only if counters enabled) */
     double   ext_ms, mis_ms, shadow_ms; /* trace_ms split: continuation / MIS closest-hit launches, any-hit launches
                                            (only if agpt_render_params::enable_timing) */
+    uint64_t answered_rays;   /* of closest_rays: Scene::Intersect calls of the reference that the production path settles without
+                                 a traversal, with the same result for the image -- MIS queries (integrator.h:76-88) towards a
+                                 sphere light whose ray misses the light's sphere, and the ray after the last bounce of a path
+                                 whose hit nothing reads (integrator.h:139-150).  0 with enable_counters = 1 (reference order). */
 } agpt_stats;
 
 /* parameters of one agpt_render call = MyApp::Tick's per-pixel loop (myapp.cpp:163-175) for a tile */

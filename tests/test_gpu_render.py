@@ -87,3 +87,31 @@ def test_lens_and_mirror_and_depth():
     d.set_camera([-1.46, 1.16, -4.64], [0, 0, 0], [0, 1, 0], 1.0, 45.0, 0.1)
     compare(d, 96, 96, 2, max_depth=3)
     compare(d, 64, 64, 1, max_depth=0)
+
+
+def test_answered_rays_are_counted_not_traced():
+    """The production path settles two kinds of the reference's Scene::Intersect calls without a traversal -- MIS queries whose ray
+    misses the sampled sphere light (integrator.h:76-88) and the ray after a path's last bounce, whose hit nothing reads
+    (integrator.h:139-150) -- and still counts them: image and ray totals equal the oracle's, which traces every one of them; the
+    reference-order instrumented run traces them too (answered_rays == 0) and gives the same image."""
+    desc = ag.scenes.scene_c1()
+    W, H, spp = 96, 64, 2
+    g = gpu_scene(desc)
+    o = oracle_scene(desc, 5)
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        oacc, ost = o.render(W, H, spp, rng_mode=ob.RNG_PER_SAMPLE, threads=8)
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    pt = ag.PathTracer(5)
+    fast, fst = pt.render_to_host(g, W, H, spp)
+    inst, ist = pt.render_to_host(g, W, H, spp, counters=True)
+    own, cst = pt.render_to_host(g, W, H, spp, counters=2)
+    g.close()
+    assert fast.tobytes() == inst.tobytes() == own.tobytes()
+    assert np.array_equal(fast[..., :3].view(np.uint32), oacc[..., :3].view(np.uint32))
+    assert (fst.closest_rays, fst.anyhit_rays) == (ost.closest_rays, ost.anyhit_rays) == (ist.closest_rays, ist.anyhit_rays)
+    assert ist.answered_rays == 0
+    assert 0 < fst.answered_rays < fst.closest_rays and cst.answered_rays == fst.answered_rays
+    # the work the production kernel counts for itself is less than the reference's recursion does: the difference is those rays
+    assert cst.interior_visits < ist.interior_visits
