@@ -860,6 +860,7 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         rcn.seed_base = rp->seed_base; rcn.max_depth = rp->max_depth;
         rcn.accum_pitch = rp->accum_pitch; rcn.accum_row0 = rp->accum_row0; rcn.NP = NP;
         rcn.mis_mode = mis_mode ? 1 : 0;
+        rcn.answer_rays = (mis_mode && !rp->trace_all_rays) ? 1 : 0;
         rcn.il_block = rp->interleave_block; rcn.il_world = rp->interleave_world; rcn.il_rank = rp->interleave_rank;
         const uint32_t total = NP * (uint32_t)rcn.S;
         int cur = 0;

@@ -60,6 +60,7 @@ struct RenderConsts {
     uint32_t NP;              // pixels of the tile this call renders (w * rows)
     int32_t il_block, il_world, il_rank;  // row-block interleave (il_block == 0: off)
     int32_t mis_mode;                     // 0: MIS rays traced as closest-hit (mis_hit), 1: as MIS queries (mis_ok)
+    int32_t answer_rays;                  // 1: ray queries that cannot reach the image are counted, not traced
 };
 
 // local pixel index -> film pixel (x, y) and the accumulator element it adds into
@@ -1223,7 +1224,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                             // settles most of the queries of the two sphere lights.  (The ray still counts as the
                             // Scene::Intersect call the reference makes.)
                             bool reach = true;
-                            if (rc.mis_mode && light.type == AGPT_LIGHT_AREA) {
+                            if (rc.answer_rays && light.type == AGPT_LIGHT_AREA) {
                                 const DevPrim& LS = sc.prims[light.shape];
                                 TraceRay qr;
                                 qr.O = mO;
@@ -1256,7 +1257,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                     if (!(flags & PF_PENDING)) beta = beta * fac;
                     flags = (flags & ~PF_SPECULAR) | (sampledSpecular ? PF_SPECULAR : 0u);
                     flags = (flags & ~PF_BOUNCE_MASK) | ((bounces + 1) & PF_BOUNCE_MASK);
-                    if (rc.mis_mode && (int)(bounces + 1) >= rc.max_depth && !sampledSpecular) {
+                    if (rc.answer_rays && (int)(bounces + 1) >= rc.max_depth && !sampledSpecular) {
                         // The ray that would follow ends the path whatever it hits: at the next vertex the loop adds emission
                         // only after a specular bounce (integrator.h:139-147) and breaks on `bounces >= maxDepth` (:150) before
                         // anything else looks at the intersection.  The reference still makes that Scene::Intersect call; its

@@ -264,14 +264,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(desc, steps, warmup, spp_, gather):
+    def measure(desc, steps, warmup, spp_, gather, trace_all=False):
         """warmup + `steps` timed passes over one workload; returns (dt, sums, scene, last full accumulator)."""
         scene = desc.instantiate(ag.Scene(ctx))
 
         def step(timing):
             local.zero_()
             st = pt.render(scene, W, H, spp_, local.data_ptr(), accum_pitch=W, samples_per_batch=args.samples_per_batch,
-                           timing=timing, interleave=interleave)
+                           timing=timing, interleave=interleave, trace_all_rays=trace_all)
             tot = dict(closest=st.closest_rays, anyhit=st.anyhit_rays, answered=st.answered_rays, trace_ms=st.trace_ms, ext_ms=st.ext_ms, mis_ms=st.mis_ms,
                        shadow_ms=st.shadow_ms, total_ms=st.total_ms, launches=st.trace_launches, iterations=st.iterations)
             full = tiles.gather_to_rank0(local, W, H, rank, world, out_bufs=gather_bufs) if gather else None
@@ -345,6 +345,19 @@ def main():
             "image_mean_rgb": [round(x, 6) for x in img_mean] if img_mean else None,
         }
     scene.close()
+
+    if world == 1 and not args.no_secondary:
+        # the same workload with every ray query of the reference sent through the BVH (agpt_render_params::trace_all_rays):
+        # the image and the ray totals are identical, only the 30 % of the queries that cannot reach the image are traced too
+        dta, sumsa, scenea, _ = measure(desc, 2, 1, spp, False, trace_all=True)
+        raysa = float(sumsa["closest"] + sumsa["anyhit"])
+        out["all_rays_traversed"] = {
+            "value": round(raysa / dta / 1e6, 2), "unit": "Mrays/s", "steps": 2, "warmup": 1, "ms_per_step": round(dta / 2 * 1e3, 2),
+            "rays_per_step": int(raysa / 2), "rays_answered_without_traversal_per_step": int(sumsa["answered"] / 2),
+            "note": "agpt_render_params::trace_all_rays = 1: the headline run answers, without a traversal, the reference's ray "
+                    "queries whose result cannot reach the image (DESIGN.md 5.0); this run traces them as well",
+        }
+        scenea.close()
 
     if world == 1 and args.workload == "c3" and not args.no_secondary:
         # BASELINE configs[4]'s scene on the same film: the configuration whose trace-time data exceeds the Infinity Cache

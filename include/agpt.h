@@ -110,6 +110,10 @@ typedef struct {
      * accum is the rank's COMPACT buffer: block j of this rank occupies rows [j*block, j*block+h_j), flipped inside the
      * block like Accumulator::AddSample; accum_row0 is ignored. */
     int32_t interleave_block, interleave_world, interleave_rank;
+    int32_t trace_all_rays;       /* 1 = send every Scene::Intersect call of the reference through the BVH.  By default (0) the
+                                   * production path only COUNTS the two kinds of call whose answer cannot reach the image (MIS
+                                   * queries whose ray misses the sampled sphere light, the ray after a path's last bounce; see
+                                   * agpt_stats::answered_rays): same image bit for bit, same ray totals, less work */
 } agpt_render_params;
 
 const char* agpt_last_error(void);

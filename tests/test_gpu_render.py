@@ -115,3 +115,18 @@ def test_answered_rays_are_counted_not_traced():
     assert 0 < fst.answered_rays < fst.closest_rays and cst.answered_rays == fst.answered_rays
     # the work the production kernel counts for itself is less than the reference's recursion does: the difference is those rays
     assert cst.interior_visits < ist.interior_visits
+
+
+def test_trace_all_rays_gives_the_same_image_and_totals():
+    """agpt_render_params::trace_all_rays: every ray query of the reference goes through the BVH; image, ray totals and outliers
+    equal the default run's, answered_rays is 0."""
+    desc = ag.scenes.scene_c1()
+    W, H, spp = 80, 60, 2
+    g = gpu_scene(desc)
+    pt = ag.PathTracer(5)
+    fast, fst = pt.render_to_host(g, W, H, spp)
+    full, ast = pt.render_to_host(g, W, H, spp, trace_all_rays=True)
+    g.close()
+    assert fast.tobytes() == full.tobytes()
+    assert (fst.closest_rays, fst.anyhit_rays, fst.outliers) == (ast.closest_rays, ast.anyhit_rays, ast.outliers)
+    assert ast.answered_rays == 0 and fst.answered_rays > 0
