@@ -307,13 +307,13 @@ def main():
 
     rays_local = float(sums["closest"] + sums["anyhit"])
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
-    r_all = torch.tensor([rays_local], dtype=torch.float64, device=dev)
+    r_all = torch.tensor([rays_local, float(sums["answered"])], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(r_all, op=dist.ReduceOp.SUM)
     dt_max = float(t_all.item())
-    rays_total = float(r_all.item())
+    rays_total, answered_total = float(r_all[0].item()), float(r_all[1].item())
 
     if rank == 0:
         # counter pass outside the timed region: the production kernels count the records they fetch on a 2-spp sample of
@@ -335,10 +335,10 @@ def main():
                 "sharding": "8-row blocks round-robin, one RCCL gather to rank 0 per step" if world > 1 else "single GPU",
                 "rays_per_step": int(rays_total / args.steps), "rays_per_sample": round(rays_total / args.steps / (W * H * spp), 2),
                 # rays = the reference algorithm's ray queries (Scene::Intersect / IntersectP calls, equal to the CPU oracle's
-                # count); this many of them per step (rank 0's share) are settled exactly without a traversal: MIS queries towards
+                # count); this many of them per step are settled exactly without a traversal: MIS queries towards
                 # a sphere light whose ray misses the light's sphere, and the ray after a path's last bounce whose hit nothing reads
-                "rays_answered_without_traversal_per_step": int(sums["answered"] / args.steps),
-                "traversed_mrays_s": round((rays_total - sums["answered"] * (rays_total / max(rays_local, 1.0))) / dt_max / 1e6, 2),
+                "rays_answered_without_traversal_per_step": int(answered_total / args.steps),
+                "traversed_mrays_s": round((rays_total - answered_total) / dt_max / 1e6, 2),
                 "msamples_per_s": round(W * H * spp * args.steps / dt_max / 1e6, 2),
             },
             "roofline": roofline_block(sums, cst, rays_local, args.steps, wl_key),
