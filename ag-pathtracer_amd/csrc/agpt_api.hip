@@ -79,8 +79,8 @@ struct agpt_ctx {
     DevBuf<float4> ext_o, ext_d, sh_o, sh_d, mis_o, mis_d, beta4, L4, fac4, c1, c2;
     DevBuf<DevHit> hit, mis_hit;
     DevBuf<uint32_t> occluded, mis_ok;
-    DevBuf<uint32_t> q[2][4];
-    DevBuf<uint32_t> qcounts;   // 2 x 4 queue lengths
+    DevBuf<uint32_t> q[2][AGPT_NQUEUES];
+    DevBuf<uint32_t> qcounts;   // 2 x AGPT_NQUEUES queue lengths
     DevBuf<uint32_t> work;      // work-queue heads of the persistent trace launches
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
@@ -277,7 +277,7 @@ int agpt_init(int device, agpt_ctx** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
-    HIP_TRY(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void**)&c->host_pinned, 2 * AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t)));
     const char* fg = getenv("AGPT_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
     if (const char* mc = getenv("AGPT_MIS_CLOSEST")) c->mis_closest = mc[0] == '1';
@@ -306,7 +306,7 @@ void agpt_destroy(agpt_ctx* c) {
     c->occluded.release();
     c->mis_ok.release();
     for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 4; j++) c->q[i][j].release();
+        for (int j = 0; j < AGPT_NQUEUES; j++) c->q[i][j].release();
     c->qcounts.release();
     c->spill.release();
     c->work.release();
@@ -673,8 +673,8 @@ int agpt_device_upload(agpt_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 
 // ---- hot path -----------------------------------------------------------------------------------------------
-// bytes of pool state per path: 11 float4 arrays + 2 hit arrays (16 B) + 2 flag words + 8 queue words
-#define AGPT_BYTES_PER_PATH (11 * 16 + 2 * 16 + 2 * 4 + 8 * 4)
+// bytes of pool state per path: 11 float4 arrays + 2 hit arrays (16 B) + 2 flag words + 2 x AGPT_NQUEUES queue words
+#define AGPT_BYTES_PER_PATH (11 * 16 + 2 * 16 + 2 * 4 + 2 * AGPT_NQUEUES * 4)
 static void release_pool(agpt_ctx* c) {
     for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4, &c->c1,
                               &c->c2})
@@ -684,7 +684,7 @@ static void release_pool(agpt_ctx* c) {
     c->occluded.release();
     c->mis_ok.release();
     for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 4; j++) c->q[i][j].release();
+        for (int j = 0; j < AGPT_NQUEUES; j++) c->q[i][j].release();
     c->cand_mask.release();
     c->cand_chunks.release();
     c->pool_paths = 0;
@@ -705,9 +705,9 @@ static int ensure_pool(agpt_ctx* c, size_t paths, int n_prims) {
     if ((rc = c->occluded.ensure(paths))) return rc;
     if ((rc = c->mis_ok.ensure(paths))) return rc;
     for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < AGPT_NQUEUES; j++)
             if ((rc = c->q[i][j].ensure(paths))) return rc;
-    if ((rc = c->qcounts.ensure(8 * AGPT_QSTRIDE))) return rc;
+    if ((rc = c->qcounts.ensure(2 * AGPT_NQUEUES * AGPT_QSTRIDE))) return rc;
     if ((rc = c->work.ensure(4096))) return rc;
     if ((rc = c->counters.ensure(1))) return rc;
     c->pool_paths = paths;
@@ -839,7 +839,8 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     Queues q[2];
     for (int i = 0; i < 2; i++) {
         q[i].active = c->q[i][0].p; q[i].ext = c->q[i][1].p; q[i].mis = c->q[i][2].p; q[i].shadow = c->q[i][3].p;
-        q[i].counts = c->qcounts.p + 4 * AGPT_QSTRIDE * i;
+        q[i].resolve = c->q[i][4].p;
+        q[i].counts = c->qcounts.p + AGPT_NQUEUES * AGPT_QSTRIDE * i;
     }
     const int count = rp->enable_counters == 2 ? 2 : (rp->enable_counters != 0 ? 1 : 0);
     const bool mis_mode = use_fast_trace(c, s->dev, count) && !c->mis_closest;
@@ -871,13 +872,15 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         int planned = rp->max_depth + 2;
         for (int it = 0;; it++) {
             if (it >= planned) {
-                HIP_TRY(hipMemcpyAsync(c->host_pinned, q[cur].counts, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                // (active count and, 4 counters further on, the resolve count)
+                HIP_TRY(hipMemcpyAsync(c->host_pinned, q[cur].counts, (4 * AGPT_QSTRIDE + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                       c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
-                if (c->host_pinned[0] == 0) break;
+                if (c->host_pinned[0] == 0 && c->host_pinned[4 * AGPT_QSTRIDE] == 0) break;
                 if (it > 4096) return fail(AGPT_ERR_LIMIT, "agpt_render: path did not terminate");
             }
             const int nxt = cur ^ 1;
-            HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, 4 * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
+            HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
             HIP_TRY(hipMemsetAsync(c->work.p, 0, 3 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
             launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
             if (mis_mode)
@@ -889,6 +892,8 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
                 hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
             else
                 hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
+            // (independent of k_shade: different paths)
+            hipLaunchKernelGGL(k_resolve_pending, dim3(c->num_cus * 8), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur]);
             cur = nxt;
             iterations++;
             launches += 3;

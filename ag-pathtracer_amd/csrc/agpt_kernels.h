@@ -47,8 +47,10 @@ struct PathBuffers {
 #endif // work-queue frontiers per trace launch (one per XCD), AGPT_QSTRIDE words apart
 struct Queues {
     uint32_t *active, *ext, *mis, *shadow;   // path ids
-    uint32_t* counts;                        // [q * AGPT_QSTRIDE]: q = 0 active, 1 ext, 2 mis, 3 shadow
+    uint32_t* resolve;                       // ended paths whose last light sample is still to be added (k_resolve_pending)
+    uint32_t* counts;                        // [q * AGPT_QSTRIDE]: q = 0 active, 1 ext, 2 mis, 3 shadow, 4 resolve
 };
+#define AGPT_NQUEUES 5
 #define QCOUNT(q, i) ((q).counts[(i) * AGPT_QSTRIDE])
 
 struct RenderConsts {
@@ -933,6 +935,7 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
         QCOUNT(q, 1) = total;
         QCOUNT(q, 2) = 0;
         QCOUNT(q, 3) = 0;
+        QCOUNT(q, 4) = 0;
     }
 }
 
@@ -943,9 +946,38 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
 #define SB_EXT 2u
 #define SB_MIS 4u
 #define SB_SHADOW 8u
-#define SB_SHADED 16u
-#define SB_MIS_ANSWERED 32u   // a MIS query answered in k_shade (counted as the Scene::Intersect call it replaces, not enqueued)
-#define SB_RAY_ANSWERED 64u   // a continuation ray whose hit nothing reads (same bookkeeping)
+#define SB_RESOLVE 16u        // (bits 0..4 = the queue the path is appended to, in Queues order)
+#define SB_SHADED 32u
+#define SB_MIS_ANSWERED 64u   // a MIS query answered in k_shade (counted as the Scene::Intersect call it replaces, not enqueued)
+#define SB_RAY_ANSWERED 128u  // a continuation ray whose hit nothing reads (same bookkeeping)
+
+// The light sample a vertex left pending (EstimateDirect's two terms, integrator.h:38-105), now that its shadow ray and its
+// MIS query have been traced: c1 if the shadow ray got through, c2 if the MIS query's answer is yes.
+__device__ __forceinline__ v3 pending_light_sample(const DevScene& sc, const RenderConsts& rc, const PathBuffers& pb, uint32_t pid,
+                                                   uint32_t flags, uint32_t was_occluded, uint32_t was_mis_ok, float4 c1_4, float4 c2_4,
+                                                   float4 f4) {
+    v3 Ld = V3s(0.f);
+    if (flags & PF_PEND_C1) {
+        if (!was_occluded) {  // VisibilityTester::Unoccluded, lights.cpp:10-12
+            Ld = Ld + V3(c1_4.x, c1_4.y, c1_4.z);
+        }
+    }
+    if (flags & PF_PEND_C2) {
+        uint32_t light = __float_as_uint(f4.w);
+        bool add;
+        if (rc.mis_mode) {
+            add = was_mis_ok != 0;
+        } else if (uint32_t hid = pb.mis_hit[pid].id; hid != AGPT_HIT_MISS) {  // integrator.h:82-85: hit shape's area light must be the sampled light
+            int hp = (hid & AGPT_HIT_SPHERE) ? (int)(hid & 0x7FFFFFFFu)
+                                             : (int)__float_as_uint(sc.tri_shade[4 * (size_t)hid + 3].w);
+            add = sc.prims[hp].arealight == (int)light;
+        } else {  // :86-87 light.Le(ray): non-zero only for an IsInfinite() light
+            add = sc.lights[light].type != AGPT_LIGHT_AREA;
+        }
+        if (add) Ld = Ld + V3(c2_4.x, c2_4.y, c2_4.z);
+    }
+    return Ld;
+}
 
 // developer build -DAGPT_SHADE_CLOCK: s_memtime stamps at the phase boundaries of shade_path, summed over waves into
 // counters->dbg[56..63] (phase k ends at SCK(k); the stamp waits for outstanding memory so a phase owns its own latency)
@@ -980,26 +1012,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
     SCK(0);   // records arrived
     // ---- resolve the previous vertex' UniformSampleOneLight (integrator.h:38-105) ------------------
     if (flags & PF_PENDING) {
-        v3 Ld = V3s(0.f);
-        if (flags & PF_PEND_C1) {
-            if (!was_occluded) {  // VisibilityTester::Unoccluded, lights.cpp:10-12
-                Ld = Ld + V3(c1_4.x, c1_4.y, c1_4.z);
-            }
-        }
-        if (flags & PF_PEND_C2) {
-            uint32_t light = __float_as_uint(f4.w);
-            bool add;
-            if (rc.mis_mode) {
-                add = was_mis_ok != 0;
-            } else if (uint32_t hid = pb.mis_hit[pid].id; hid != AGPT_HIT_MISS) {  // integrator.h:82-85: hit shape's area light must be the sampled light
-                int hp = (hid & AGPT_HIT_SPHERE) ? (int)(hid & 0x7FFFFFFFu)
-                                                 : (int)__float_as_uint(sc.tri_shade[4 * (size_t)hid + 3].w);
-                add = sc.prims[hp].arealight == (int)light;
-            } else {  // :86-87 light.Le(ray): non-zero only for an IsInfinite() light
-                add = sc.lights[light].type != AGPT_LIGHT_AREA;
-            }
-            if (add) Ld = Ld + V3(c2_4.x, c2_4.y, c2_4.z);
-        }
+        const v3 Ld = pending_light_sample(sc, rc, pb, pid, flags, was_occluded, was_mis_ok, c1_4, c2_4, f4);
         float lightPdf = 1.f / sc.n_lights;           // integrator.h:100,104
         L = L + beta * (Ld / lightPdf);               // integrator.h:166
         if (!(flags & PF_DEAD)) beta = beta * V3(f4.x, f4.y, f4.z);  // integrator.h:176
@@ -1285,7 +1298,11 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             }
         }
     }
-    if ((bits & SB_EXT) || (flags & PF_PENDING)) bits |= SB_ACTIVE;
+    // a path that goes on has a continuation ray; one that has ended but still owes its last light sample (which waits for
+    // this iteration's shadow ray / MIS query) goes to the resolve queue: k_resolve_pending adds the sample without the
+    // records, the lanes and the code of a full k_shade pass
+    if (bits & SB_EXT) bits |= SB_ACTIVE;
+    else if (flags & PF_PENDING) bits |= SB_RESOLVE;
     b4.x = beta.x; b4.y = beta.y; b4.z = beta.z; b4.w = __uint_as_float(flags);
     l4.x = L.x; l4.y = L.y; l4.z = L.z; l4.w = __uint_as_float(rng);
     pb.beta4[pid] = b4;
@@ -1301,9 +1318,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 #ifndef SHADE_U
 #define SHADE_U 4
 #endif
-#ifndef AGPT_SHADE_BLOCK_TILES
-#define AGPT_SHADE_BLOCK_TILES 0   // developer A/B: 1 = block-wide tiles of AGPT_BLOCK * SHADE_U entries with barriers (round-1 form)
-#endif
+
 // 3 waves/SIMD: the register allocator is capped at 168 VGPRs (48 spilled to scratch); measured 127 ms per C3 step
 // against 140 ms at 2 waves (217 VGPRs, no spills) and 151 ms at 4 waves (96 spilled).
 #ifndef AGPT_SHADE_WAVES
@@ -1341,11 +1356,7 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
     }
     __shared__ uint32_t s_pid[SHADE_U][AGPT_BLOCK];
     __shared__ uint32_t s_bits[SHADE_U][AGPT_BLOCK];
-    __shared__ uint32_t s_cnt[4][SHADE_U * 4];
-    __shared__ uint32_t s_off[4][SHADE_U * 4];
     const uint32_t n_active = QCOUNT(qin, 0);
-    const uint32_t tile_size = AGPT_BLOCK * SHADE_U;
-    const uint32_t n_tiles = (n_active + tile_size - 1) / tile_size;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t shaded = 0, mis_answered = 0;
@@ -1354,68 +1365,15 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
     unsigned long long sck_last = __builtin_amdgcn_s_memtime();
     const unsigned long long sck_begin = sck_last;
 #endif
-#if AGPT_SHADE_BLOCK_TILES
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-#pragma unroll 1
-        for (int u = 0; u < SHADE_U; ++u) {
-#ifdef AGPT_SHADE_CLOCK
-            { const unsigned long long n0 = __builtin_amdgcn_s_memtime(); sck_acc[7] += n0 - sck_last; sck_last = n0; }   // queue appends, barriers
-#endif
-            const uint32_t qi = tile * tile_size + (uint32_t)u * AGPT_BLOCK + (uint32_t)tid;
-            uint32_t pid = 0, bits = 0;
-            if (qi < n_active) {
-                pid = qin.active[qi];
-                bits = shade_path(sc, rc, pb, pid SCK_ARGS);
-            }
-            s_pid[u][tid] = pid;
-            s_bits[u][tid] = bits;
-            shaded += (bits & SB_SHADED) ? 1u : 0u;
-            mis_answered += ((bits & SB_MIS_ANSWERED) ? 1u : 0u) + ((bits & SB_RAY_ANSWERED) ? 1u : 0u);
-        }
-        for (int u = 0; u < SHADE_U; ++u) {
-            const uint32_t bits = s_bits[u][tid];
-            for (int q = 0; q < 4; ++q) {
-                unsigned long long m = __ballot((bits >> q) & 1u);
-                if (lane == 0) s_cnt[q][u * 4 + wave] = (uint32_t)__popcll(m);
-            }
-        }
-        __syncthreads();
-        if (tid < 4) {
-            uint32_t run = 0;
-            uint32_t offs[SHADE_U * 4];
-            for (int k = 0; k < SHADE_U * 4; ++k) {
-                offs[k] = run;
-                run += s_cnt[tid][k];
-            }
-            uint32_t base = run ? atomicAdd(&QCOUNT(qout, tid), run) : 0u;
-            for (int k = 0; k < SHADE_U * 4; ++k) s_off[tid][k] = base + offs[k];
-        }
-        __syncthreads();
-        for (int u = 0; u < SHADE_U; ++u) {
-            const uint32_t bits = s_bits[u][tid];
-            const uint32_t pid = s_pid[u][tid];
-            for (int q = 0; q < 4; ++q) {
-                const bool pred = (bits >> q) & 1u;
-                unsigned long long m = __ballot(pred);
-                if (pred) {
-                    uint32_t* qq = q == 0 ? qout.active : (q == 1 ? qout.ext : (q == 2 ? qout.mis : qout.shadow));
-                    qq[s_off[q][u * 4 + wave] + (uint32_t)__popcll(m & lt_mask)] = pid;
-                }
-            }
-        }
-        __syncthreads();
-    }
-#else
     // Wave-private tiles of 64 * SHADE_U queue entries: the wave shades them, counts its appends per queue with ballots and
     // reserves the slots with one atomic per queue (lanes 0..3, one queue each).  No block barrier: with block-wide tiles
     // the three __syncthreads per tile made every wave wait for the slowest of its block -- 10 % of the kernel's wave
     // time (s_memtime phase clocks) -- while 4x the atomics (one per queue per 256 paths) stay far below the ~11 ns per
     // same-line atomic that had made per-wave-per-64-paths appends the bottleneck.
-    (void)n_tiles; (void)s_cnt; (void)s_off;
     const uint32_t wtile = 64u * SHADE_U;
     const uint32_t n_wtiles = (n_active + wtile - 1) / wtile;
     for (uint32_t t = blockIdx.x * (AGPT_BLOCK / 64) + (uint32_t)wave; t < n_wtiles; t += gridDim.x * (AGPT_BLOCK / 64)) {
-        uint32_t total[4] = {0, 0, 0, 0};
+        uint32_t total[AGPT_NQUEUES] = {0, 0, 0, 0, 0};
 #pragma unroll 1
         for (int u = 0; u < SHADE_U; ++u) {
 #ifdef AGPT_SHADE_CLOCK
@@ -1431,28 +1389,28 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
             s_bits[u][tid] = bits;
             shaded += (bits & SB_SHADED) ? 1u : 0u;
             mis_answered += ((bits & SB_MIS_ANSWERED) ? 1u : 0u) + ((bits & SB_RAY_ANSWERED) ? 1u : 0u);
-            for (int q = 0; q < 4; ++q) total[q] += (uint32_t)__popcll(__ballot((bits >> q) & 1u));
+            for (int q = 0; q < AGPT_NQUEUES; ++q) total[q] += (uint32_t)__popcll(__ballot((bits >> q) & 1u));
         }
-        const uint32_t my_total = lane == 0 ? total[0] : (lane == 1 ? total[1] : (lane == 2 ? total[2] : total[3]));
+        uint32_t my_total = total[0];
+        for (int q = 1; q < AGPT_NQUEUES; ++q) my_total = lane == q ? total[q] : my_total;
         uint32_t base = 0;
-        if (lane < 4 && my_total) base = atomicAdd(&QCOUNT(qout, lane), my_total);
-        uint32_t run[4];
-        for (int q = 0; q < 4; ++q) run[q] = (uint32_t)__shfl((int)base, q);
+        if (lane < AGPT_NQUEUES && my_total) base = atomicAdd(&QCOUNT(qout, lane), my_total);
+        uint32_t run[AGPT_NQUEUES];
+        for (int q = 0; q < AGPT_NQUEUES; ++q) run[q] = (uint32_t)__shfl((int)base, q);
         for (int u = 0; u < SHADE_U; ++u) {
             const uint32_t bits = s_bits[u][tid];
             const uint32_t pid = s_pid[u][tid];
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < AGPT_NQUEUES; ++q) {
                 const bool pred = (bits >> q) & 1u;
                 const unsigned long long m = __ballot(pred);
                 if (pred) {
-                    uint32_t* qq = q == 0 ? qout.active : (q == 1 ? qout.ext : (q == 2 ? qout.mis : qout.shadow));
+                    uint32_t* qq = q == 0 ? qout.active : (q == 1 ? qout.ext : (q == 2 ? qout.mis : (q == 3 ? qout.shadow : qout.resolve)));
                     qq[run[q] + (uint32_t)__popcll(m & lt_mask)] = pid;
                 }
                 run[q] += (uint32_t)__popcll(m);
             }
         }
     }
-#endif
 #ifdef AGPT_SHADE_CLOCK
     if (lane == 0) {
         for (int k = 0; k < 8; ++k) atomicAdd(&counters->dbg[56 + k], sck_acc[k]);
@@ -1468,6 +1426,29 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
     if (lane == 0 && mis_answered) {
         atomicAdd(&counters->closest_rays, (unsigned long long)mis_answered);   // MIS queries are Scene::Intersect calls
         atomicAdd(&counters->answered, (unsigned long long)mis_answered);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Paths that have ended (MaxDepth reached, miss, black sample) while their last vertex' light sample was still waiting for its
+// shadow ray / MIS query: add the sample (integrator.h:166) and let the path go.  They used to ride through a whole
+// k_shade pass for this -- after the last bounce that is EVERY path of the batch: 10 records loaded, 3 wave slots per SIMD.
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_resolve_pending(DevScene sc, RenderConsts rc, PathBuffers pb, Queues qin) {
+    const uint32_t n = QCOUNT(qin, 4);
+    for (uint32_t i = blockIdx.x * AGPT_BLOCK + threadIdx.x; i < n; i += gridDim.x * AGPT_BLOCK) {
+        const uint32_t pid = qin.resolve[i];
+        const float4 b4 = pb.beta4[pid];
+        float4 l4 = pb.L4[pid];
+        const float4 f4 = pb.fac4[pid];
+        const uint32_t was_occluded = pb.occluded[pid], was_mis_ok = pb.mis_ok[pid];
+        const float4 c1_4 = pb.c1[pid], c2_4 = pb.c2[pid];
+        const uint32_t flags = __float_as_uint(b4.w);
+        const v3 Ld = pending_light_sample(sc, rc, pb, pid, flags, was_occluded, was_mis_ok, c1_4, c2_4, f4);
+        const float lightPdf = 1.f / sc.n_lights;
+        const v3 L = V3(l4.x, l4.y, l4.z) + V3(b4.x, b4.y, b4.z) * (Ld / lightPdf);
+        l4.x = L.x; l4.y = L.y; l4.z = L.z;
+        pb.L4[pid] = l4;
     }
 }
 
