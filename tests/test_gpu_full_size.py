@@ -71,6 +71,12 @@ def test_c3_full_scene_1080p_tile_vs_oracle_and_invariances():
             assert st_r.samples == W * tiles.local_rows(H, r, world) * spp
             bufs.append(ctx.download(ptr, (H, W, 4))[:rows].copy())
         assert tiles.deinterleave(bufs, W, H, world).tobytes() == full.tobytes()
+    # (b5) the production path answers ~30 % of the reference's ray queries without tracing them: with every query
+    #      traced the film and the ray totals are the same, bit for bit
+    traced, st_all = pt.render_to_host(g, W, H, spp, trace_all_rays=True)
+    assert traced.tobytes() == full.tobytes()
+    assert (st_all.closest_rays, st_all.anyhit_rays) == (st.closest_rays, st.anyhit_rays)
+    assert st_all.answered_rays == 0 and 0.2 * st.rays < st.answered_rays < 0.4 * st.rays
     ctx.free(ptr)
     g.close()
 
