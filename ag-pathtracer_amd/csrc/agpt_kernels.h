@@ -67,8 +67,22 @@ struct RenderConsts {
 
 // local pixel index -> film pixel (x, y) and the accumulator element it adds into
 __device__ __forceinline__ void pixel_of(const RenderConsts& rc, uint32_t p, int& x, int& y, size_t& accum_index) {
-    const uint32_t row = p / (uint32_t)rc.w;
-    x = rc.x0 + (int)(p - row * (uint32_t)rc.w);
+    // Local pixel order: 8x8-pixel blocks, row-major inside a block and over the blocks, when the region's width and its number
+    // of rows are multiples of 8 (1080p is; so is every rank's share of 8-row blocks) -- a wave then starts on a compact 8x8
+    // patch of the film instead of a 64x1 strip, and the queues keep that order.  Plain row-major otherwise.  (The order is
+    // invisible outside: RNG streams and accumulator elements are addressed by the film pixel.)
+    const uint32_t w = (uint32_t)rc.w, n_rows = rc.NP / w;
+    uint32_t row, col;
+    if (((w | n_rows) & 7u) == 0u) {
+        const uint32_t blk = p >> 6, inner = p & 63u, per_row = w >> 3;
+        const uint32_t brow = blk / per_row;
+        row = brow * 8u + (inner >> 3);
+        col = (blk - brow * per_row) * 8u + (inner & 7u);
+    } else {
+        row = p / w;
+        col = p - row * w;
+    }
+    x = rc.x0 + (int)col;
     if (rc.il_block == 0) {
         y = rc.y0 + (int)row;
         accum_index = (size_t)((rc.H - 1 - y) - rc.accum_row0) * (size_t)rc.accum_pitch + (size_t)x;
