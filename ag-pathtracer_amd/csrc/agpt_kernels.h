@@ -1,12 +1,13 @@
 // agpt_kernels.h -- the gfx950 kernels of the wavefront path tracer.
 //
-// One agpt_render batch = S samples x NP tile pixels paths, path id = s*NP + p.  Per iteration:
+// One agpt_render batch = S samples x NP tile pixels paths (path order: sample_group / pixel_of below).  Per iteration:
 //     k_trace_fast<0>(ext queue)     continuation rays, closest hit                     -> hit[]
 //     k_trace_fast<2>(mis queue)     BSDF-sampled MIS rays as exact early-exit queries  -> mis_ok[]
 //     k_trace_fast<1>(shadow queue)  NEE shadow rays, any hit                           -> occluded[]
 //     k_shade(active queue)          resolves the previous vertex' NEE, then PathTracer::Li's loop body for the
 //                                    new hit; appends to the next iteration's queues with one atomic per queue per
 //                                    wave-private 256-path tile (ballot counts, order-preserving offsets)
+//     k_resolve_pending(resolve q.)  ended paths: adds the last vertex' light sample once its rays have been traced
 // (the instrumented / fallback k_trace traces MIS rays as closest hits into mis_hit[]).  Scenes with more than 64
 // primitives run k_candidates (top-level tree over Scene::primitives) in front of each trace launch.  The trace kernels are
 // persistent: a fixed grid of waves pulls 64-ray chunks off the queue; queue lengths stay on the device (no host round
