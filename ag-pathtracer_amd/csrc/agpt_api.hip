@@ -236,6 +236,20 @@ static void launch_trace(agpt_ctx* c, const DevScene& sc, const uint32_t* queue,
                            work_head, ro, rd, hits, occ, c->counters.p);
 }
 
+static void release_pool(agpt_ctx* c) {
+    for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4, &c->c1,
+                              &c->c2})
+        b->release();
+    c->hit.release();
+    c->mis_hit.release();
+    c->occluded.release();
+    c->mis_ok.release();
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < AGPT_NQUEUES; j++) c->q[i][j].release();
+    c->cand_mask.release();
+    c->cand_chunks.release();
+    c->pool_paths = 0;
+}
 static hipEvent_t next_event(agpt_ctx* c) {
     if (c->tev_used == c->tev.size()) {
         hipEvent_t e = nullptr;
@@ -298,15 +312,7 @@ void agpt_destroy(agpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4,
-                              &c->c1, &c->c2})
-        b->release();
-    c->hit.release();
-    c->mis_hit.release();
-    c->occluded.release();
-    c->mis_ok.release();
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < AGPT_NQUEUES; j++) c->q[i][j].release();
+    release_pool(c);   // every per-path buffer (one list, shared with the batch-halving path of agpt_render)
     c->qcounts.release();
     c->spill.release();
     c->work.release();
@@ -675,24 +681,13 @@ int agpt_device_upload(agpt_ctx* c, void* dst, const void* src, size_t bytes) {
 // ---- hot path -----------------------------------------------------------------------------------------------
 // bytes of pool state per path: 11 float4 arrays + 2 hit arrays (16 B) + 2 flag words + 2 x AGPT_NQUEUES queue words
 #define AGPT_BYTES_PER_PATH (11 * 16 + 2 * 16 + 2 * 4 + 2 * AGPT_NQUEUES * 4)
-static void release_pool(agpt_ctx* c) {
-    for (DevBuf<float4>* b : {&c->ext_o, &c->ext_d, &c->sh_o, &c->sh_d, &c->mis_o, &c->mis_d, &c->beta4, &c->L4, &c->fac4, &c->c1,
-                              &c->c2})
-        b->release();
-    c->hit.release();
-    c->mis_hit.release();
-    c->occluded.release();
-    c->mis_ok.release();
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < AGPT_NQUEUES; j++) c->q[i][j].release();
-    c->cand_mask.release();
-    c->cand_chunks.release();
-    c->pool_paths = 0;
-}
 // extra pool bytes per path for a scene: the candidate words of lists longer than 64 primitives (k_candidates)
 static size_t candidate_bytes_per_path(int n_prims) { return n_prims > 64 ? 4 + 8 * (size_t)((n_prims + 63) / 64) : 0; }
 static int ensure_pool(agpt_ctx* c, size_t paths, int n_prims) {
     int rc;
+    // the pool never shrinks: a small call after a large one keeps the capacity (agpt_render sizes its batches by it, and the
+    // candidate words are laid out [chunk][pool_paths])
+    paths = std::max(paths, c->pool_paths);
     if (n_prims > 64) {
         if ((rc = c->cand_chunks.ensure(paths))) return rc;
         if ((rc = c->cand_mask.ensure(paths * (size_t)((n_prims + 63) / 64)))) return rc;
@@ -1197,17 +1192,24 @@ int agpt_gather_tiles(agpt_comm* m, const float* local_accum_dev, int width, int
             int rc = m->staging.ensure(slot * (size_t)(world - 1));
             if (rc) return rc;
             // grouped point-to-point: every peer's buffer travels its own direct xGMI link to rank 0 (not a ring)
+            // (a group that was started is always ended, also when a call inside it fails: the first error is reported)
             e = R->GroupStart();
-            for (int r = 1; r < world && e == ncclSuccess; r++) {
-                const size_t n = (size_t)rows_of_rank(height, block_rows, world, r) * (size_t)width * 4;
-                if (n) e = R->Recv(m->staging.p + slot * (size_t)(r - 1), n, ncclFloat, r, m->comm, c->stream);
+            if (e == ncclSuccess) {
+                for (int r = 1; r < world && e == ncclSuccess; r++) {
+                    const size_t n = (size_t)rows_of_rank(height, block_rows, world, r) * (size_t)width * 4;
+                    if (n) e = R->Recv(m->staging.p + slot * (size_t)(r - 1), n, ncclFloat, r, m->comm, c->stream);
+                }
+                const ncclResult_t e_end = R->GroupEnd();
+                if (e == ncclSuccess) e = e_end;
             }
-            if (e == ncclSuccess) e = R->GroupEnd();
         } else {
             const size_t n = (size_t)rows_of_rank(height, block_rows, world, m->rank) * (size_t)width * 4;
             e = R->GroupStart();
-            if (e == ncclSuccess && n) e = R->Send(local_accum_dev, n, ncclFloat, 0, m->comm, c->stream);
-            if (e == ncclSuccess) e = R->GroupEnd();
+            if (e == ncclSuccess) {
+                if (n) e = R->Send(local_accum_dev, n, ncclFloat, 0, m->comm, c->stream);
+                const ncclResult_t e_end = R->GroupEnd();
+                if (e == ncclSuccess) e = e_end;
+            }
         }
         if (e != ncclSuccess) return fail(AGPT_ERR_DEVICE, std::string("agpt_gather_tiles: ") + R->GetErrorString(e));
     }

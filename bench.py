@@ -12,15 +12,20 @@ over that whole sample budget: jitter -> Camera::GetRay -> PathTracer::Li -> Acc
 
 N > 1: STRONG scaling by default -- the same 1080p/64spp film is split over the ranks (8-row blocks dealt round-robin,
 every rank renders its blocks for the whole 64 spp) and the step ends with the RCCL gather of the per-rank tile buffers
-to rank 0.  `--scaling weak` keeps the per-GPU sample count instead (64*N spp in total).  value = rays traced by all
-ranks / max-over-ranks time.
+to rank 0 through the library's own collective (`agpt_gather_tiles`; `--gather torch` uses torch.distributed.gather
+instead).  `--scaling weak` keeps the per-GPU sample count instead (64*N spp in total).
+
+value = rays that ENTERED a trace kernel (k_trace_fast), summed over all ranks / max-over-ranks wall time.  The reference
+algorithm issues more Scene::Intersect calls than that: the production path settles, without a traversal, the calls whose
+answer cannot reach the image -- those are NOT in `value`; the rate that counts them is reported beside
+it as `config.reference_queries_mrays_s`, and `config.msamples_per_s` is the rate of finished camera samples.
 
 The printed JSON line carries
   * `roofline` for the dominant kernels (the persistent trace kernels k_trace_fast<closest / MIS query / any-hit>, timed
     live per launch with HIP events on the launch stream).  The path is bound by VALU issue under divergence, not by
     HBM (the 37 MB scene lives in L2 / Infinity Cache): `bound: "issue"`, achieved = VALU wave-instructions per second
-    (instructions per ray from the committed rocprofv3 SQ pass of this exact kernel build and workload,
-    profiles/pmc_*.json, times the rays traced in the timed region), peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64
+    (instructions per traversed ray from the committed rocprofv3 SQ pass of this exact kernel build and workload,
+    profiles/pmc_*.json, times the rays traversed in the timed region), peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64
     instruction.  The HBM view is reported next to it under `hbm`: the algorithmic bytes of SURVEY.md 8(d) (counted by
     the timed kernel itself on the same rays) and the measured memory-side traffic of the same PMC profile.  Every
     profile-derived number is null when the committed profile does not match the running kernel build / workload;
@@ -135,24 +140,26 @@ def cpu_baseline(desc, W, H, max_depth, budget_s=12.0):
                   % (sppn, stn.rays, dtn, cores, spp1, st1.rays, dt1),
         "single_thread_value": round(st1.rays / dt1 / 1e6, 3),
         "rays_per_sample": round(stn.rays / float(stn.samples), 2),
+        "note": "the CPU path traverses every Scene::Intersect / IntersectP call of the reference, so its rate is a rate of traversed "
+                "rays like `value` (its rays per sample equal config.reference_queries_per_sample, not rays_traversed_per_sample)",
     }
 
 
 def roofline_block(sums, cst, rays, steps, workload_key):
     """The roofline object for one measured workload.  sums: HIP-event sums over the timed steps; cst: work counters of
-    the production trace kernels on the same queue contents (counter pass outside the timed region); rays: rays this
-    rank traced in the timed region."""
-    crays = float(cst.rays)
-    b_one_root, b_all_roots = algorithmic_bytes(cst.closest_rays, cst.anyhit_rays, cst.root_tests, cst.interior_visits,
-                                                cst.tri_tests)
+    the production trace kernels on the same queue contents (counter pass outside the timed region); rays: rays that
+    entered a trace kernel on this rank in the timed region.  Every per-ray figure is per TRAVERSED ray."""
+    crays = float(cst.rays - cst.answered_rays)
+    b_one_root, b_all_roots = algorithmic_bytes(cst.closest_rays - cst.answered_rays, cst.anyhit_rays, cst.root_tests,
+                                                cst.interior_visits, cst.tri_tests)
     bpr = b_one_root / crays
     trace_s = sums["trace_ms"] / 1e3
     launches = max(1, int(sums["launches"]))
     avg_launch_s = trace_s / launches
     prof = load_pmc_profile(workload_key)
     tr = prof.get("trace", {}) if prof else {}
-    insts_per_ray = tr.get("valu_insts_per_ray")
-    hbm_per_ray = tr.get("hbm_bytes_per_ray")
+    insts_per_ray = tr.get("valu_insts_per_traversed_ray")
+    hbm_per_ray = tr.get("hbm_bytes_per_traversed_ray")
     algo_gbs = bpr * rays / trace_s / 1e9 if trace_s > 0 else None
     issue = insts_per_ray * rays / trace_s / 1e9 if insts_per_ray and trace_s > 0 else None
     traffic_launch = hbm_per_ray * rays / launches if hbm_per_ray else None
@@ -177,6 +184,7 @@ def roofline_block(sums, cst, rays, steps, workload_key):
                  "no committed PMC profile matches this kernel build (%s) and workload (%s): profile-derived fields are null"
                  % (kernel_build_id(), workload_key),
         "issue": issue_view,
+        "per_ray_basis": "rays that entered a trace kernel (queries answered without a traversal excluded)",
         "valu_insts_per_ray": round(insts_per_ray, 1) if insts_per_ray else None,
         "wait_fraction": tr.get("wait_fraction"), "lane_utilisation": tr.get("lane_utilisation"),
         "hbm": {
@@ -219,6 +227,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C5 secondary measurement")
     ap.add_argument("--samples-per-batch", type=int, default=0)
+    ap.add_argument("--gather", default="agpt", choices=["agpt", "torch"],
+                    help="N > 1: agpt = the library's own collective agpt_gather_tiles (RCCL grouped send/recv + de-interleave "
+                         "kernel, the path a C++ host uses; default), torch = torch.distributed.gather + torch de-interleave")
     args = ap.parse_args()
 
     import torch
@@ -253,8 +264,24 @@ def main():
     pt = ag.PathTracer(MAXD)
     rows = tiles.max_local_rows(H, world)
     local = torch.zeros((rows, W, 4), dtype=torch.float32, device=dev)
-    # gather buffers live outside the timed step
-    gather_bufs = tiles.alloc_gather_buffers(local, rank, world)
+    # The exchange at the end of a step.  Default: the product's own collective (agpt_gather_tiles) -- rank 0 creates the
+    # ncclUniqueId through the C ABI, torch.distributed only carries its 128 bytes to the other ranks.  RCCL wants one GPU
+    # per rank, so the several-ranks-on-one-GPU rehearsal (AGPT_BENCH_BACKEND=gloo) gathers through torch instead.
+    gather_mode = args.gather if (world > 1 and backend == "nccl") else ("torch" if world > 1 else "none")
+    comm = None
+    full_accum = None
+    gather_bufs = None
+    if gather_mode == "agpt":
+        import torch.distributed as dist
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(ag.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        comm = ag.Comm(ctx, world, rank, unique_id=idt.cpu().numpy().tobytes())
+        if rank == 0:
+            full_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    elif gather_mode == "torch":
+        gather_bufs = tiles.alloc_gather_buffers(local, rank, world)   # receive buffers live outside the timed step
     # one agpt_render call per step and rank: the whole film at N = 1, this rank's interleaved 8-row blocks otherwise
     interleave = None if world == 1 else (tiles.BLOCK_ROWS, world, rank)
 
@@ -264,7 +291,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(desc, steps, warmup, spp_, gather, trace_all=False):
+    def gather():
+        if gather_mode == "agpt":
+            comm.gather_tiles(local.data_ptr(), W, H, tiles.BLOCK_ROWS, full_accum.data_ptr() if rank == 0 else 0)
+            return full_accum
+        return tiles.gather_to_rank0(local, W, H, rank, world, out_bufs=gather_bufs)
+
+    def measure(desc, steps, warmup, spp_, do_gather, trace_all=False):
         """warmup + `steps` timed passes over one workload; returns (dt, sums, scene, last full accumulator)."""
         scene = desc.instantiate(ag.Scene(ctx))
 
@@ -274,7 +307,7 @@ def main():
                            timing=timing, interleave=interleave, trace_all_rays=trace_all)
             tot = dict(closest=st.closest_rays, anyhit=st.anyhit_rays, answered=st.answered_rays, trace_ms=st.trace_ms, ext_ms=st.ext_ms, mis_ms=st.mis_ms,
                        shadow_ms=st.shadow_ms, total_ms=st.total_ms, launches=st.trace_launches, iterations=st.iterations)
-            full = tiles.gather_to_rank0(local, W, H, rank, world, out_bufs=gather_bufs) if gather else None
+            full = gather() if do_gather else None
             return tot, full
 
         for _ in range(warmup):
@@ -295,6 +328,19 @@ def main():
         dt = time.perf_counter() - t0
         return dt, sums, scene, acc
 
+    def rates(sums, dt, steps, samples_per_step):
+        """The three rates of one measurement (this process' rays; the headline sums over ranks below)."""
+        queries = float(sums["closest"] + sums["anyhit"])
+        traversed = queries - float(sums["answered"])
+        return {
+            "value": round(traversed / dt / 1e6, 2), "unit": "Mrays/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
+            "rays_traversed_per_step": int(traversed / steps),
+            "reference_queries_per_step": int(queries / steps),
+            "rays_answered_without_traversal_per_step": int(sums["answered"] / steps),
+            "reference_queries_mrays_s": round(queries / dt / 1e6, 2),
+            "msamples_per_s": round(samples_per_step * steps / dt / 1e6, 2),
+        }
+
     if args.workload == "c5":
         desc = ag.scenes.scene_c5(scale=args.scene_scale, aspect=W / float(H))
         wl_name = "BASELINE configs[4] geometry: 5M-triangle multi-mesh colonnade field, all-metal GGX"
@@ -305,15 +351,17 @@ def main():
 
     dt, sums, scene, acc = measure(desc, args.steps, args.warmup, spp, True)
 
-    rays_local = float(sums["closest"] + sums["anyhit"])
+    queries_local = float(sums["closest"] + sums["anyhit"])
+    traversed_local = queries_local - float(sums["answered"])
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
-    r_all = torch.tensor([rays_local, float(sums["answered"])], dtype=torch.float64, device=dev)
+    r_all = torch.tensor([queries_local, float(sums["answered"])], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(r_all, op=dist.ReduceOp.SUM)
     dt_max = float(t_all.item())
-    rays_total, answered_total = float(r_all[0].item()), float(r_all[1].item())
+    queries_total, answered_total = float(r_all[0].item()), float(r_all[1].item())
+    traversed_total = queries_total - answered_total
 
     if rank == 0:
         # counter pass outside the timed region: the production kernels count the records they fetch on a 2-spp sample of
@@ -321,7 +369,7 @@ def main():
         cst = pt.render(scene, W, H, min(spp, 2), local.data_ptr(), accum_pitch=W, counters=2, interleave=interleave)
         img_mean = acc[..., :3].double().mean(dim=(0, 1)).div(spp).tolist() if acc is not None else None
         out = {
-            "metric": "Mrays/sec (primary+secondary) at 1080p/64spp", "value": round(rays_total / dt_max / 1e6, 2),
+            "metric": "Mrays/sec (primary+secondary) at 1080p/64spp", "value": round(traversed_total / dt_max / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": args.scaling,
@@ -332,48 +380,47 @@ def main():
                                (" (%d spp x %d GPU shares)" % (args.spp, world)) if weak else
                                (" split over %d GPUs" % world if world > 1 else "")),
                 "triangles": desc.n_tris, "resolution": [W, H], "spp": spp,
-                "sharding": "8-row blocks round-robin, one RCCL gather to rank 0 per step" if world > 1 else "single GPU",
-                "rays_per_step": int(rays_total / args.steps), "rays_per_sample": round(rays_total / args.steps / (W * H * spp), 2),
-                # rays = the reference algorithm's ray queries (Scene::Intersect / IntersectP calls, equal to the CPU oracle's
-                # count); this many of them per step are settled exactly without a traversal: MIS queries towards
-                # a sphere light whose ray misses the light's sphere, and the ray after a path's last bounce whose hit nothing reads
+                "sharding": ("8-row blocks round-robin, one gather to rank 0 per step: %s"
+                             % ("agpt_gather_tiles (C ABI: RCCL grouped send/recv over xGMI + k_deinterleave)" if gather_mode == "agpt"
+                                else "torch.distributed.gather (%s) + torch de-interleave" % backend)) if world > 1 else "single GPU",
+                # value counts the rays that entered a trace kernel (k_trace_fast launches: continuation / MIS query / shadow):
+                # value x ms_per_step = rays_traversed_per_step.  The reference algorithm's Scene::Intersect / IntersectP calls
+                # (equal to the CPU oracle's count) are reference_queries_per_step; the difference is settled exactly without a
+                # traversal (MIS queries towards a sphere light whose ray misses the light's sphere, the ray after a path's last
+                # bounce whose hit nothing reads: DESIGN.md 5.0) and earns no Mrays/s.
+                "rays_traversed_per_step": int(traversed_total / args.steps),
+                "rays_traversed_per_sample": round(traversed_total / args.steps / (W * H * spp), 2),
+                "reference_queries_per_step": int(queries_total / args.steps),
+                "reference_queries_per_sample": round(queries_total / args.steps / (W * H * spp), 2),
                 "rays_answered_without_traversal_per_step": int(answered_total / args.steps),
-                "traversed_mrays_s": round((rays_total - answered_total) / dt_max / 1e6, 2),
+                "reference_queries_mrays_s": round(queries_total / dt_max / 1e6, 2),
                 "msamples_per_s": round(W * H * spp * args.steps / dt_max / 1e6, 2),
             },
-            "roofline": roofline_block(sums, cst, rays_local, args.steps, wl_key),
+            "roofline": roofline_block(sums, cst, traversed_local, args.steps, wl_key),
             "image_mean_rgb": [round(x, 6) for x in img_mean] if img_mean else None,
         }
     scene.close()
 
     if world == 1 and not args.no_secondary:
         # the same workload with every ray query of the reference sent through the BVH (agpt_render_params::trace_all_rays):
-        # the image and the ray totals are identical, only the 30 % of the queries that cannot reach the image are traced too
-        dta, sumsa, scenea, _ = measure(desc, 2, 1, spp, False, trace_all=True)
-        raysa = float(sumsa["closest"] + sumsa["anyhit"])
-        out["all_rays_traversed"] = {
-            "value": round(raysa / dta / 1e6, 2), "unit": "Mrays/s", "steps": 2, "warmup": 1, "ms_per_step": round(dta / 2 * 1e3, 2),
-            "rays_per_step": int(raysa / 2), "rays_answered_without_traversal_per_step": int(sumsa["answered"] / 2),
-            "note": "agpt_render_params::trace_all_rays = 1: the headline run answers, without a traversal, the reference's ray "
-                    "queries whose result cannot reach the image (DESIGN.md 5.0); this run traces them as well",
-        }
+        # the image and the query totals are identical; the queries that cannot reach the image are traversed too
+        dta, sumsa, scenea, _ = measure(desc, args.steps, args.warmup, spp, False, trace_all=True)
+        out["all_rays_traversed"] = dict(rates(sumsa, dta, args.steps, W * H * spp), warmup=args.warmup,
+            note="agpt_render_params::trace_all_rays = 1: every Scene::Intersect / IntersectP call of the reference goes through the "
+                 "BVH (the headline run settles the ones whose result cannot reach the image without a traversal, DESIGN.md 5.0)")
         scenea.close()
 
     if world == 1 and args.workload == "c3" and not args.no_secondary:
         # BASELINE configs[4]'s scene on the same film: the configuration whose trace-time data exceeds the Infinity Cache
         desc5 = ag.scenes.scene_c5(aspect=W / float(H))
-        dt5, sums5, scene5, _ = measure(desc5, 2, 1, spp, False)
+        dt5, sums5, scene5, _ = measure(desc5, args.steps, args.warmup, spp, False)
         cst5 = pt.render(scene5, W, H, min(spp, 2), local.data_ptr(), accum_pitch=W, counters=2)
-        rays5 = float(sums5["closest"] + sums5["anyhit"])
-        out["secondary"] = {
-            "workload": "BASELINE configs[4] geometry: 5M-triangle multi-mesh scene, all-metal GGX + MIS, %d tris / %d primitives, "
-                        "%dx%d, %d spp (one GPU's film; the config's 4K / 1024 spp budget is that of 8 GPUs)"
-                        % (desc5.n_tris, desc5.n_prims, W, H, spp),
-            "value": round(rays5 / dt5 / 1e6, 2), "unit": "Mrays/s", "steps": 2, "warmup": 1, "ms_per_step": round(dt5 / 2 * 1e3, 2),
-            "rays_answered_without_traversal_per_step": int(sums5["answered"] / 2),
-            "traversed_mrays_s": round((rays5 - sums5["answered"]) / dt5 / 1e6, 2),
-            "roofline": roofline_block(sums5, cst5, rays5, 2, "c5:%dx%d:%dspp:world1:scale1" % (W, H, spp)),
-        }
+        trav5 = float(sums5["closest"] + sums5["anyhit"] - sums5["answered"])
+        out["secondary"] = dict(rates(sums5, dt5, args.steps, W * H * spp), warmup=args.warmup,
+            workload="BASELINE configs[4] geometry: 5M-triangle multi-mesh scene, all-metal GGX + MIS, %d tris / %d primitives, "
+                     "%dx%d, %d spp (one GPU's film; the config's 4K / 1024 spp budget is that of 8 GPUs)"
+                     % (desc5.n_tris, desc5.n_prims, W, H, spp),
+            roofline=roofline_block(sums5, cst5, trav5, args.steps, "c5:%dx%d:%dspp:world1:scale1" % (W, H, spp)))
         scene5.close()
 
     if rank == 0:
@@ -384,6 +431,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+    if comm is not None:
+        comm.close()
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
     ctx.close()
 

@@ -180,3 +180,66 @@ def test_c5_five_million_triangles_17_meshes():
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     finally:
         ob.set_trig_mode(ob.TRIG_LIBM)
+
+
+# ---- the configurations at their own sample counts ---------------------------------------------------------------------------
+# With 64 spp a wave of the path tracer starts as ONE pixel's 64 samples and k_accumulate adds them line-wise: the code path
+# bench.py times.  The oracle runs the reference's loop (myapp.cpp:163-175 per sample, AddSample in sample order myapp.h:17-19).
+def assert_tiles_match(desc, full, W, H, spp, tile_list):
+    for tile in tile_list:
+        oacc, _ = oracle_tile(desc, W, H, spp, tile)
+        a, b = tile_rows(full, H, tile), tile_rows(oacc, H, tile)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), tile
+
+
+def test_c3_1080p_at_its_64_spp_oracle_tiles_and_rank_share():
+    """BASELINE config 3 at its own budget, 1920x1080 / 64 spp (bench.py's step): two 96x54 oracle tiles bit-exact; one rank's
+    interleaved share of an 8-rank split at 64 spp equals its rows of the full film."""
+    W, H, spp = 1920, 1080, 64
+    desc = ag.scenes.scene_c3()
+    g = gpu_scene(desc)
+    pt = ag.PathTracer(5)
+    full, st = pt.render_to_host(g, W, H, spp)
+    assert st.samples == W * H * spp and st.outliers == 0
+    ctx = g.ctx
+    world, r = 8, 3
+    rows = tiles.local_rows(H, r, world)
+    ptr = ctx.alloc(W * H * 16)
+    ctx.memset(ptr, 0, W * H * 16)
+    st_r = pt.render(g, W, H, spp, ptr, interleave=(tiles.BLOCK_ROWS, world, r))
+    share = ctx.download(ptr, (H, W, 4))[:rows].copy()
+    ctx.free(ptr)
+    g.close()
+    assert st_r.samples == W * rows * spp
+    for (y0, h, off) in tiles.row_blocks(H, r, world):
+        assert share[off:off + h].tobytes() == full[H - y0 - h:H - y0].tobytes()
+    assert_tiles_match(desc, full, W, H, spp, [(912, 500, 96, 54), (200, 90, 96, 54)])
+
+
+def test_c2_720p_at_its_16_spp_oracle_tiles():
+    """BASELINE config 2 at its own budget, 1280x720 / 16 spp (bundles of G = 16 samples)."""
+    W, H, spp = 1280, 720, 16
+    desc = ag.scenes.scene_c2()
+    g = gpu_scene(desc)
+    full, st = ag.PathTracer(5).render_to_host(g, W, H, spp)
+    g.close()
+    assert st.samples == W * H * spp and st.outliers == 0
+    assert_tiles_match(desc, full, W, H, spp, [(600, 330, 96, 54), (400, 500, 64, 64)])
+
+
+def test_c3_192_spp_in_mixed_batches():
+    """192 spp of the C3 film through batches of 64 (default), 128 + 64 and 48 x 4 samples (sample groups 64, 64 + 64, 16): the
+    three films are the same bit for bit, and an oracle tile at 192 spp pins them."""
+    W, H, spp = 1920, 1080, 192
+    desc = ag.scenes.scene_c3()
+    g = gpu_scene(desc)
+    pt = ag.PathTracer(5)
+    a, sa = pt.render_to_host(g, W, H, spp, samples_per_batch=64)
+    b, sb = pt.render_to_host(g, W, H, spp, samples_per_batch=128)
+    assert a.tobytes() == b.tobytes() and sa.rays == sb.rays
+    del b
+    c, sc = pt.render_to_host(g, W, H, spp, samples_per_batch=48)
+    g.close()
+    assert a.tobytes() == c.tobytes() and sa.rays == sc.rays
+    del c
+    assert_tiles_match(desc, a, W, H, spp, [(1000, 420, 64, 32)])

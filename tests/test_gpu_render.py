@@ -130,3 +130,43 @@ def test_trace_all_rays_gives_the_same_image_and_totals():
     assert fast.tobytes() == full.tobytes()
     assert (fst.closest_rays, fst.anyhit_rays, fst.outliers) == (ast.closest_rays, ast.anyhit_rays, ast.outliers)
     assert ast.answered_rays == 0 and fst.answered_rays > 0
+
+
+# ---- the path order of the timed configuration ----------------------------------------------------------------------------
+# A batch orders its paths as ((s / G) * NP + p) * G + s % G with G = sample_group(S) = the largest power of two <= 64 dividing
+# the batch's sample count, and k_accumulate adds a pixel's samples line-wise (4 per 64-B line) when G % 4 == 0.  bench.py
+# runs S = 64 -> G = 64: the cases below hold that order -- and the mixed ones a batch split produces -- against the oracle's
+# loop (myapp.cpp:163-175 over samples, AddSample order myapp.h:17-19) on films that take the 8x8-block pixel order (64x64) and
+# the row-major one (80x60).
+@pytest.mark.parametrize("W,H", [(64, 64), (80, 60)])
+@pytest.mark.parametrize("spp,spb", [(4, 0), (12, 0), (64, 0), (64, 48), (64, 16), (192, 64), (192, 128), (70, 0)])
+def test_sample_bundles_match_oracle(W, H, spp, spb):
+    """G = 4 (spp 4, 12), 64 (spp 64), 16 + 16 (48 + 16 split), 16 (x4), 64 (x3), 64 + 64 (128 + 64), 2 (spp 70): pixels
+    bit-identical to the oracle and equal ray totals."""
+    compare(ag.scenes.scene_c1(), W, H, spp, spb=spb)
+
+
+def test_sample_bundle_splits_agree():
+    """64 spp in one batch (one wave per pixel's 64 samples) == 64 x 1 spp accumulated progressively == a two-rank interleave
+    of 8-row blocks at 64 spp, gathered -- bit for bit, on both pixel orders."""
+    from ag_pathtracer_amd import tiles
+    desc = ag.scenes.scene_c1()
+    g = gpu_scene(desc)
+    pt = ag.PathTracer(5)
+    ctx = g.ctx
+    for (W, H) in ((64, 64), (80, 60)):
+        full, st = pt.render_to_host(g, W, H, 64)
+        ptr = ctx.alloc(W * H * 16)
+        ctx.memset(ptr, 0, W * H * 16)
+        rays = 0
+        for s in range(64):
+            rays += pt.render(g, W, H, 1, ptr, spp_begin=s).rays
+        assert ctx.download(ptr, (H, W, 4)).tobytes() == full.tobytes() and rays == st.rays
+        bufs = []
+        for r in range(2):
+            ctx.memset(ptr, 0, W * H * 16)
+            pt.render(g, W, H, 64, ptr, interleave=(tiles.BLOCK_ROWS, 2, r))
+            bufs.append(ctx.download(ptr, (H, W, 4))[:tiles.max_local_rows(H, 2)].copy())
+        assert tiles.deinterleave(bufs, W, H, 2).tobytes() == full.tobytes()
+        ctx.free(ptr)
+    g.close()

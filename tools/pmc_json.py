@@ -5,8 +5,8 @@
 
 Per kernel family (trace = k_trace_fast<*>, shade = k_shade): counter sums over all dispatches of the profiled step,
 and the per-ray figures bench.py scales by the rays of its timed region:
-    valu_insts_per_ray   SQ_INSTS_VALU / rays                    (wave-instructions)
-    hbm_bytes_per_ray    (read + write bytes leaving the L2s) / rays, with
+    valu_insts_per_traversed_ray   SQ_INSTS_VALU / rays            (wave-instructions)
+    hbm_bytes_per_traversed_ray    (read + write bytes leaving the L2s) / rays, with
         read  = 32*RDREQ_32B + 128*RDREQ_128B + 64*(RDREQ - RDREQ_32B - RDREQ_128B)   (TCC_EA0 = the L2s' memory-side requests)
         write = 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B)
       each counter group collected in its own --pmc pass with --kernel-trace only, as MI355X_MICROARCH.md's HBM / rocprofv3
@@ -15,7 +15,8 @@ and the per-ray figures bench.py scales by the rays of its timed region:
     wait_fraction        SQ_WAIT_ANY / SQ_WAVE_CYCLES            (both in quad-cycles, summed over waves)
     lane_utilisation     SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
     issue_fraction_profiled  SQ_INSTS_VALU * 2 cycles / (1024 SIMDs * kernel duration * clock) in the profiled run itself
-rays = closest + any-hit rays of the profiled step (bench line of the same pass).  kernel_build = bench.kernel_build_id().
+rays = the rays that entered a trace kernel in the profiled step (config.rays_traversed_per_step of the bench line of the same
+pass; the reference's ray queries that are answered without a traversal are not in it).  kernel_build = bench.kernel_build_id().
 """
 import collections
 import csv
@@ -59,11 +60,11 @@ rays = None
 for f in sorted(glob.glob(os.path.join(d, "*.log"))):
     try:
         line = json.loads(open(f).read().strip().splitlines()[-1])
-        rays = float(line["config"]["rays_per_step"])
+        rays = float(line["config"]["rays_traversed_per_step"])
     except Exception:  # noqa: BLE001
         continue
 assert rays, "no bench line found next to the counter files"
-res = {"kernel_build": bench.kernel_build_id(), "workload": workload, "rays_profiled": rays,
+res = {"kernel_build": bench.kernel_build_id(), "workload": workload, "rays_traversed_profiled": rays,
        "how": "tools/gpu_pmc.sh: rocprofv3 --pmc <one group per pass> --kernel-trace -- python3 bench.py --steps 1 --warmup 0"}
 for k, c in agg.items():
     rd = 32 * c.get("TCC_EA0_RDREQ_32B_sum", 0) + 128 * c.get("TCC_EA0_RDREQ_128B_sum", 0) + 64 * (
@@ -71,8 +72,8 @@ for k, c in agg.items():
     wr = 64 * c.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * (c.get("TCC_EA0_WRREQ_sum", 0) - c.get("TCC_EA0_WRREQ_64B_sum", 0))
     e = {"launches": launches[k], "counters": dict(sorted(c.items()))}
     if c.get("SQ_INSTS_VALU"):
-        e["valu_insts_per_ray"] = c["SQ_INSTS_VALU"] / rays
-        e["salu_insts_per_ray"] = c.get("SQ_INSTS_SALU", 0) / rays
+        e["valu_insts_per_traversed_ray"] = c["SQ_INSTS_VALU"] / rays
+        e["salu_insts_per_traversed_ray"] = c.get("SQ_INSTS_SALU", 0) / rays
         if c.get("SQ_WAVE_CYCLES"):
             e["wait_fraction"] = round(c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 4)
         if c.get("SQ_ACTIVE_INST_VALU"):
@@ -83,7 +84,7 @@ for k, c in agg.items():
     if rd or wr:
         e["hbm_read_bytes"] = rd
         e["hbm_write_bytes"] = wr
-        e["hbm_bytes_per_ray"] = (rd + wr) / rays
+        e["hbm_bytes_per_traversed_ray"] = (rd + wr) / rays
     res[k] = e
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in res.items() if isinstance(v, dict)}))
