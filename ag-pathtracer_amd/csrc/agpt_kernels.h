@@ -385,6 +385,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
        unsigned long long ts_refills = 0; unsigned long long ts_refilled = 0; unsigned long long ts_pref = 0;)
     TCK(unsigned long long tk_refill = 0, tk_vote = 0, tk_bmem = 0, tk_balu = 0, tk_c = 0, tk_a = 0; const unsigned long long tk_begin = TCK_NOW();)
 
+#if defined(AGPT_X_DUMMYLOAD) || defined(AGPT_X_PF_CHILDREN) || defined(AGPT_X_PF_LEAF)
+    float x_pf0 = 0.f, x_pf1 = 0.f;   // developer experiments (tools/build_variant.py): registers of touch loads
+#endif
     uint32_t pfa_off = 0;       // lane 0: offset returned by the pending frontier atomic (stage A)
     uint32_t pfa_seg = 0;
     bool pfa_valid = false;     // wave-uniform, like every *_valid / *_n below
@@ -621,7 +624,30 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     // waves in the middle of their arithmetic (-1.5 ms per C3 step on the closest-hit and MIS launches; the
                     // short any-hit steps lose 0.3 ms with it)
                     if (MODE != 1) __builtin_amdgcn_s_setprio(1);
+#ifdef AGPT_X_ROOT_LDS
+                    // root pairs (a mesh's root-box test, 11 % of the interior steps) come from the LDS copy of the primitive
+                    // records instead of through the vector L1
+                    NodePair np;
+                    if (LIST || cur < rootpair_base) {
+                        np = load_pair(sc, cur);
+                    } else {
+                        const uint32_t rk = (cur - rootpair_base) >> 1;
+                        const float4 ra = s_prim[2 * rk], rb = s_prim[2 * rk + 1];
+                        np.n0.x = ra.x; np.n0.y = ra.x; np.n0.z = ra.y; np.n0.w = ra.y;
+                        np.n1.x = ra.z; np.n1.y = ra.z; np.n1.z = rb.x; np.n1.w = rb.x;
+                        np.n2.x = rb.y; np.n2.y = rb.y; np.n2.z = rb.z; np.n2.w = rb.z;
+                        np.n3.x = rb.w; np.n3.y = rb.w; np.n3.z = 0.f; np.n3.w = 0.f;
+                    }
+#else
                     const NodePair np = load_pair(sc, cur);
+#endif
+#ifdef AGPT_X_DUMMYLOAD
+                    {   // one more lookup of the same line (plain cached load through a laundered pointer)
+                        // (inline asm: its own destination register, no interaction with the compiler's waitcnt bookkeeping; the
+                        // compiler's vmcnt(0) for the pair record covers it, loads return in order)
+                        asm volatile("global_load_dword v95, %0, off offset:60" : : "v"(sc.nodes + 2 * (size_t)cur) : "memory", "v95");
+                    }
+#endif
                     if (MODE != 1) {
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_s_setprio(0);
@@ -629,11 +655,28 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     TCK(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk_bmem += TCK_NOW() - tk_v1;)
                     float dl, dr;
                     bool hl, hr;
+                    const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
+#ifdef AGPT_X_PF_CHILDREN
+                    {   // touch the first line of both children's records while the slab arithmetic runs (after the whole record has
+                        // arrived: the touches are younger than it, and a wait for the record would wait for them too)
+                        asm volatile("" ::"v"(np.n0.x), "v"(np.n1.x), "v"(np.n2.x), "v"(np.n3.x));
+                        auto touch = [&](uint32_t enc) -> float {
+                            // interior children only (leaf children: AGPT_X_PF_LEAF); a leaf child re-touches this record
+                            const uint32_t k = (int32_t)enc < 0 ? cur : enc;
+                            asm volatile("global_load_dword v95, %0, off" : : "v"(sc.nodes + 2 * (size_t)k) : "memory", "v95");
+                            return 0.f;
+                        };
+                        x_pf0 = touch(encl);
+                        x_pf1 = touch(cur < rootpair_base ? encr : encl);
+                    }
+#endif
                     pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
                     if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
                         if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
                     }
-                    const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
+#ifdef AGPT_X_DUMMYLOAD
+                    asm volatile("" ::"v"(x_pf0));
+#endif
                     if (COUNT) {
                         if (cur < rootpair_base) c_int++; else c_root++;
                     }
@@ -653,6 +696,13 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         sp--;
                         cur = stack_at(sp);
                     }
+#ifdef AGPT_X_PF_LEAF
+                    // the lane has arrived at a leaf and will wait for the wave's next leaf step: start fetching its first triangle
+                    if ((int32_t)cur < 0 && (cur & AGPT_ENC_BIGLEAF) != AGPT_ENC_BIGLEAF) {
+                        const float4* tpf = sc.tri_verts + 3 * (size_t)(cur & 0x0FFFFFFFu);
+                        asm volatile("global_load_dword v94, %0, off\n\tglobal_load_dword v94, %0, off offset:44" : : "v"(tpf) : "memory", "v94");
+                    }
+#endif
                 }
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_balu += TCK_NOW() - tk_v1;)
             } else if (nC >= nA) {
@@ -664,6 +714,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     for (uint32_t i = 0; i < cnt; ++i) {
                         const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
+#ifdef AGPT_X_PF_LEAF
+                        asm volatile("" ::"v"(x_pf0), "v"(x_pf1), "v"(a.x));
+#endif
                         const v3 q0 = V3(a.x, a.y, a.z), q1 = V3(b.x, b.y, b.z), q2 = V3(c.x, c.y, c.z);
                         const uint32_t q_id = __float_as_uint(a.w), q_flags = __float_as_uint(b.w);
                         float t, b1, b2;
