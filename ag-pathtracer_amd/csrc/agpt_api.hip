@@ -926,6 +926,11 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
                          (double)d[0], (double)d[1], (double)d[2], 100 * d[0] / steps, 100 * d[1] / steps, 100 * d[2] / steps,
                          d[0] ? (double)d[3] / d[0] : 0., d[1] ? (double)d[4] / d[1] : 0., d[2] ? (double)d[5] / d[2] : 0.,
                          (double)d[6] / steps, (double)d[7], d[7] ? (double)d[8] / d[7] : 0., (double)d[9]);
+#ifndef AGPT_TRACE_CLOCK
+            std::fprintf(stderr, "[trace stats mode %d] stack pushes %.3g: to depth > 4 %.2f%%  > 6 %.3f%%  > 8 %.4f%%  > 12 %.5f%%\n", mode, (double)d[10],
+                         d[10] ? 100. * d[11] / d[10] : 0., d[10] ? 100. * d[12] / d[10] : 0., d[10] ? 100. * d[13] / d[10] : 0.,
+                         d[10] ? 100. * d[14] / d[10] : 0.);
+#endif
 #ifdef AGPT_TRACE_CLOCK
             const double tot = (double)dc.dbg[48 + mode];
             std::fprintf(stderr,

@@ -254,11 +254,48 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
     constexpr int BLOCK = AGPT_BLOCK;
+#ifdef AGPT_X_STAGED
+    constexpr bool STAGED = true;
+#else
+    constexpr bool STAGED = false;
+#endif
+    // the primitive records live in LDS for short lists unless the LDS is needed for the staged pair fetch
+    constexpr bool PRIM_LDS = !LIST && !STAGED;
     __shared__ uint32_t s_stack[DEPTH * BLOCK];
-    __shared__ float4 s_prim[LIST ? 2 : 2 * 64];
+    __shared__ float4 s_prim[PRIM_LDS ? 2 * 64 : 2];
+    // STAGED: an interior step fetches its 64-byte pair records QUAD-COOPERATIVELY through LDS-DMA: instruction j (0..3) makes
+    // the four lanes of every quad read the four 16-byte quarters of the record of the quad's lane j -- 64 contiguous bytes per
+    // quad and instruction, which the vector L1 serves as one request -- straight into row j of the wave's staging buffer; each
+    // lane then reads its own record back with 4 ds_read_b128.  (Rows padded by 16 bytes: conflict-free reads.)
+    __shared__ float4 s_stage[STAGED ? BLOCK / 64 : 1][4][STAGED ? 65 : 1];
     uint32_t* stack = s_stack + threadIdx.x;
     uint32_t* spill_col = SPILL ? spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
     const size_t spill_stride = (size_t)gridDim.x * BLOCK;
+#ifdef AGPT_STACK_RING
+    // The LDS part of a deep stack is a RING of the DEPTH newest entries: a push onto a full ring first moves the OLDEST entry it
+    // holds to the lane's HBM column, a pop below the ring's bottom reads that column.  The entries a descent pushes and pops
+    // next stay in LDS whatever the depth; only a lane that unwinds past DEPTH pending entries touches HBM.  (The round-2
+    // layout kept entries 0 .. DEPTH-1 in LDS and sent the TOP of a deep stack -- the entries in use -- to HBM.)
+    static_assert(!SPILL || (DEPTH & (DEPTH - 1)) == 0, "ring stack: DEPTH must be a power of two");
+    int slo = 0;   // lowest stack index the ring holds (entries below it are in the HBM column)
+    auto stack_push = [&](int k, uint32_t v) {
+        if (SPILL) {
+            if (k - slo == DEPTH) {
+                spill_col[(size_t)slo * spill_stride] = stack[(slo & (DEPTH - 1)) * BLOCK];
+                slo++;
+            }
+            stack[(k & (DEPTH - 1)) * BLOCK] = v;
+        } else {
+            stack[k * BLOCK] = v;
+        }
+    };
+    auto stack_at = [&](int k) -> uint32_t {
+        if (!SPILL) return stack[k * BLOCK];
+        if (k >= slo) return stack[(k & (DEPTH - 1)) * BLOCK];
+        slo = k;
+        return spill_col[(size_t)k * spill_stride];
+    };
+#else
     auto stack_push = [&](int k, uint32_t v) {
         if (!SPILL || k < DEPTH)
             stack[k * BLOCK] = v;
@@ -269,12 +306,13 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         if (!SPILL || k < DEPTH) return stack[k * BLOCK];
         return spill_col[(size_t)(k - DEPTH) * spill_stride];
     };
+#endif
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // (a value loaded through a pointer counts as divergent for the compiler: readfirstlane keeps the bookkeeping scalar)
     const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)(count_ptr ? *count_ptr : count_imm));
     const int n_prims = LIST ? 0 : sc.n_prims;   // (short lists: the primitive records live in LDS)
-    if ((int)threadIdx.x < n_prims) {
+    if (PRIM_LDS && (int)threadIdx.x < n_prims) {
         const DevPrim& P = sc.prims[threadIdx.x];
         float4 a, b;
         if (P.type == AGPT_PRIM_SPHERE) {
@@ -312,7 +350,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     uint32_t cinfo = 0;
     // the sphere of an area light as (centre, r2), wherever it sits in the primitive list
     auto light_sphere = [&](int shape, v3& c, float& r2) {
-        if (!LIST) {
+        if (PRIM_LDS) {
             const float4 sa = s_prim[2 * shape], sb = s_prim[2 * shape + 1];
             c = V3(sa.x, sa.y, sa.z);
             r2 = sb.x;
@@ -382,7 +420,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     bool any_slow = false;                  // wave-uniform: some active lane's ray needs the true-division slab test
     uint32_t c_int = 0, c_root = 0, c_tri = 0;   // COUNT
     TS(unsigned long long ts_steps[3] = {0, 0, 0}; unsigned long long ts_lanes[3] = {0, 0, 0}; unsigned long long ts_act = 0;
-       unsigned long long ts_refills = 0; unsigned long long ts_refilled = 0; unsigned long long ts_pref = 0;)
+       unsigned long long ts_refills = 0; unsigned long long ts_refilled = 0; unsigned long long ts_pref = 0;
+       uint32_t ts_push[5] = {0, 0, 0, 0, 0};)
     TCK(unsigned long long tk_refill = 0, tk_vote = 0, tk_bmem = 0, tk_balu = 0, tk_c = 0, tk_a = 0; const unsigned long long tk_begin = TCK_NOW();)
 
 #if defined(AGPT_X_DUMMYLOAD) || defined(AGPT_X_PF_CHILDREN) || defined(AGPT_X_PF_LEAF)
@@ -592,6 +631,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     hb1 = 0.f;
                     hb2 = 0.f;
                     sp = 0;
+#ifdef AGPT_STACK_RING
+                    slo = 0;
+#endif
                     cur = pick_next(mask);
                 }
             }
@@ -619,12 +661,48 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             TS(ts_act += (unsigned long long)n_active; if (!(nB >= nA && nB >= nC) && !(nC >= nA)) { ts_steps[0]++; ts_lanes[0] += nA; })
             if (nB >= nA && nB >= nC) {
                 TS(ts_steps[1]++; ts_lanes[1] += nB;)
+                if (STAGED) {
+                    // (all 64 lanes run this: a lane fetches quarters of its quad-mates' records whatever its own state is)
+                    const unsigned long long bm = __ballot(cur < CUR_B_END);
+                    float4* stage = &s_stage[threadIdx.x >> 6][0][0];
+                    if (MODE != 1) __builtin_amdgcn_s_setprio(1);
+                    // quads whose lane j is at an interior node; all four lanes of such a quad take part
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AGPT_STAGE_STEP(j)                                                                                                  \
+    {                                                                                                                       \
+        unsigned long long qj = (bm >> (j)) & 0x1111111111111111ull;                                                        \
+        qj |= qj << 1;                                                                                                      \
+        qj |= qj << 2;                                                                                                      \
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, (j) * 0x55, 0xF, 0xF, true); /* quad_perm [j,j,j,j] */ \
+        if ((qj >> lane) & 1ull) __builtin_amdgcn_global_load_lds(sc.nodes + 2 * (size_t)cj + (lane & 3), stage + 65 * (j), 16, 0, 0); \
+    }
+                    AGPT_STAGE_STEP(0)
+                    AGPT_STAGE_STEP(1)
+                    AGPT_STAGE_STEP(2)
+                    AGPT_STAGE_STEP(3)
+#undef AGPT_STAGE_STEP
+#endif
+                    if (MODE != 1) {
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 if (cur < CUR_B_END) {
                     // the wave is about to wait for these loads whatever happens: let its issue win the arbitration against
                     // waves in the middle of their arithmetic (-1.5 ms per C3 step on the closest-hit and MIS launches; the
                     // short any-hit steps lose 0.3 ms with it)
-                    if (MODE != 1) __builtin_amdgcn_s_setprio(1);
-#ifdef AGPT_X_ROOT_LDS
+                    if (MODE != 1 && !STAGED) __builtin_amdgcn_s_setprio(1);
+#ifdef AGPT_X_STAGED
+                    NodePair np;
+                    {   // the lane's record: row (lane & 3), slots 4 * quad .. 4 * quad + 3
+                        const float4* mine = &s_stage[threadIdx.x >> 6][lane & 3][lane & ~3];
+                        np.n0 = mine[0];
+                        np.n1 = mine[1];
+                        np.n2 = mine[2];
+                        np.n3 = mine[3];
+                    }
+#elif defined(AGPT_X_ROOT_LDS)
                     // root pairs (a mesh's root-box test, 11 % of the interior steps) come from the LDS copy of the primitive
                     // records instead of through the vector L1
                     NodePair np;
@@ -641,6 +719,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
 #else
                     const NodePair np = load_pair(sc, cur);
 #endif
+#ifndef AGPT_X_STAGED
 #ifdef AGPT_X_DUMMYLOAD
                     {   // one more lookup of the same line (plain cached load through a laundered pointer)
                         // (inline asm: its own destination register, no interaction with the compiler's waitcnt bookkeeping; the
@@ -652,6 +731,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_s_setprio(0);
                     }
+#endif
                     TCK(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk_bmem += TCK_NOW() - tk_v1;)
                     float dl, dr;
                     bool hl, hr;
@@ -685,6 +765,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         bool swap = ANY ? false : (dr < dl);
                         stack_push(sp, swap ? encl : encr);
                         sp++;
+                        TS(ts_push[0]++; ts_push[1] += sp > 4; ts_push[2] += sp > 6; ts_push[3] += sp > 8; ts_push[4] += sp > 12;)
                         cur = swap ? encr : encl;
                     } else if (hl) {
                         cur = encl;
@@ -774,7 +855,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     const int k = (LIST ? 64 * (int)(cinfo >> 16) : 0) + __ffsll((long long)mask) - 1;   // list index
                     mask &= mask - 1;
                     float4 pa, pb2;
-                    if (LIST) {   // (the short-list instantiation keeps these records in LDS)
+                    if (!PRIM_LDS) {   // (the short-list instantiation keeps these records in LDS)
                         const DevPrim& P = sc.prims[k];
                         const bool sphere = P.type == AGPT_PRIM_SPHERE;
                         pa.x = P.cx; pa.y = P.cy; pa.z = P.cz; pa.w = sphere ? 1.f : (P.type == AGPT_PRIM_PLANE ? 3.f : 2.f);
@@ -814,6 +895,19 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         unsigned long long* d = counters->dbg + 16 * MODE;
         for (int k = 0; k < 3; ++k) { atomicAdd(d + k, ts_steps[k]); atomicAdd(d + 3 + k, ts_lanes[k]); }
         atomicAdd(d + 6, ts_act); atomicAdd(d + 7, ts_refills); atomicAdd(d + 8, ts_refilled); atomicAdd(d + 9, ts_pref);
+    })
+#if defined(AGPT_TRACE_STATS) && !defined(AGPT_TRACE_CLOCK)
+    {   // stack-depth histogram of the pushes (per lane; slots 10..14 are the phase clocks' in the clock build)
+        unsigned long long* d = counters->dbg + 16 * MODE;
+        for (int k = 0; k < 5; ++k) {
+            uint32_t v = ts_push[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) atomicAdd(d + 10 + k, (unsigned long long)v);
+        }
+    }
+#endif
+    TS(if (lane == 0) {
+        unsigned long long* d = counters->dbg + 16 * MODE;
         TCK(atomicAdd(d + 10, tk_refill); atomicAdd(d + 11, tk_vote); atomicAdd(d + 12, tk_bmem); atomicAdd(d + 13, tk_balu);
             atomicAdd(d + 14, tk_c); atomicAdd(d + 15, tk_a); atomicAdd(counters->dbg + 48 + MODE, TCK_NOW() - tk_begin);)
     })

@@ -22,6 +22,44 @@
 // reference's own header by tests/golden/obj_cases.npz (oracle/ref_tinyobj.cpp, tests/golden/make_obj_golden.py).
 // Unlike the reference (which then indexes out of bounds), a face that references a vertex / normal / texcoord that does
 // not exist is an error here.
+//
+// Third-party notices.  The token parsers and the polygon triangulation below restate algorithms of tinyobjloader 2.0.0 (each
+// function says which); tinyobjloader is distributed under the MIT licence:
+//
+//     The MIT License (MIT)
+//     Copyright (c) 2012-2018 Syoyo Fujita and many contributors.
+//     Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//     documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+//     rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit
+//     persons to whom the Software is furnished to do so, subject to the following conditions:
+//     The above copyright notice and this permission notice shall be included in all copies or substantial portions of the
+//     Software.
+//     THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//     WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR
+//     COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//     OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+//
+// inside_polygon() is the PNPOLY point-inclusion test that tinyobjloader takes from
+// https://wrf.ecse.rpi.edu/Research/Short_Notes/pnpoly.html:
+//
+//     Copyright (c) 1970-2003, Wm. Randolph Franklin
+//     Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//     documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+//     rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit
+//     persons to whom the Software is furnished to do so, subject to the following conditions:
+//     1. Redistributions of source code must retain the above copyright notice, this list of conditions and the following
+//        disclaimers.
+//     2. Redistributions in binary form must reproduce the above copyright notice in the documentation and/or other materials
+//        provided with the distribution.
+//     3. The name of W. Randolph Franklin may not be used to endorse or promote products derived from this Software without
+//        specific prior written permission.
+//     THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//     WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR
+//     COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//     OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+//
+// inverse_transpose() evaluates the 4x4 cofactor expansion of Mesa's gluInvertMatrix (SGI Free Software License B), the
+// form the reference's mat4::Inverted uses (template/precomp.h:948-990): the operation order decides the rounded normals.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -104,235 +142,209 @@ void transform_vector(const Mat4& M, const float v[3], float out[3]) {
     out[2] = c[8] * v[0] + c[9] * v[1] + c[10] * v[2];
 }
 
-bool fix_index(int idx, int n, int* ret) {
-    if (idx > 0) { *ret = idx - 1; return true; }
-    if (idx == 0) return false;
-    *ret = n + idx;
+// ---- OBJ token parsers ---------------------------------------------------------------------------------------------------------
+// The functions from here to the end of triangulate_polygon() restate, in this file's own form, algorithms of tinyobjloader 2.0.0
+// (the header the reference vendors as tiny_obj_loader.h; MIT licence, notice at the top of this file): byte parity with what
+// the reference parses requires the same arithmetic in the same order, so the NUMERIC steps are tinyobjloader's even where the
+// control flow is not.  Per function: which of its functions is restated, and where it sits in the reference's copy.
+
+// 1-based / negative OBJ index -> 0-based (restates tinyobj::fixIndex, tiny_obj_loader.h:765-787): k > 0 counts from the start,
+// k < 0 back from the `count` elements seen so far, 0 is malformed.
+bool resolve_index(int k, int count, int* zero_based) {
+    if (k == 0) return false;
+    *zero_based = k > 0 ? k - 1 : count + k;
     return true;
 }
 
-// atoi as tinyobjloader uses it: optional blanks, optional sign, digits; anything else ends the number (0 if none)
-int c_atoi(const char* p) { return std::atoi(p); }
-
-// parseTriple (tiny_obj_loader.h:1093-1151): i, i/j/k, i//k, i/j
-bool parse_triple(const char*& token, int vsize, int vnsize, int vtsize, Corner* ret) {
-    Corner vi;
-    vi.v = vi.vt = vi.vn = -1;
-    if (!fix_index(c_atoi(token), vsize, &vi.v)) return false;
-    token += std::strcspn(token, "/ \t\r");
-    if (token[0] != '/') {
-        *ret = vi;
-        return true;
+// One face corner `v`, `v/vt`, `v//vn` or `v/vt/vn` (restates tinyobj::parseTriple, tiny_obj_loader.h:1093-1151: every number
+// through atoi, a field ends at '/', blank or CR).  Absent fields stay -1.
+bool read_corner(const char*& cur, int n_v, int n_vn, int n_vt, Corner* corner) {
+    Corner c;
+    c.v = c.vt = c.vn = -1;
+    auto field = [&cur](int count, int* dst) {
+        const bool ok = resolve_index(std::atoi(cur), count, dst);
+        cur += std::strcspn(cur, "/ \t\r");
+        return ok;
+    };
+    if (!field(n_v, &c.v)) return false;
+    if (*cur == '/') {
+        ++cur;
+        if (*cur == '/') {   // v//vn
+            ++cur;
+            if (!field(n_vn, &c.vn)) return false;
+        } else {             // v/vt[/vn]
+            if (!field(n_vt, &c.vt)) return false;
+            if (*cur == '/') {
+                ++cur;
+                if (!field(n_vn, &c.vn)) return false;
+            }
+        }
     }
-    token++;
-    if (token[0] == '/') {   // i//k
-        token++;
-        if (!fix_index(c_atoi(token), vnsize, &vi.vn)) return false;
-        token += std::strcspn(token, "/ \t\r");
-        *ret = vi;
-        return true;
-    }
-    if (!fix_index(c_atoi(token), vtsize, &vi.vt)) return false;   // i/j/k or i/j
-    token += std::strcspn(token, "/ \t\r");
-    if (token[0] != '/') {
-        *ret = vi;
-        return true;
-    }
-    token++;   // i/j/k
-    if (!fix_index(c_atoi(token), vnsize, &vi.vn)) return false;
-    token += std::strcspn(token, "/ \t\r");
-    *ret = vi;
+    *corner = c;
     return true;
 }
 
 inline bool is_digit(char x) { return static_cast<unsigned int>(x - '0') < 10u; }
 
-// tryParseDouble (tiny_obj_loader.h:836-960), operation for operation
-bool try_parse_double(const char* s, const char* s_end, double* result) {
-    if (s >= s_end) return false;
-    double mantissa = 0.0;
-    int exponent = 0;
-    char sign = '+', exp_sign = '+';
-    const char* curr = s;
-    int read = 0;
-    bool end_not_reached = false, leading_decimal_dots = false;
-    if (*curr == '+' || *curr == '-') {
-        sign = *curr;
-        curr++;
-        if ((curr != s_end) && (*curr == '.')) leading_decimal_dots = true;
-    } else if (is_digit(*curr)) {
-    } else if (*curr == '.') {
-        leading_decimal_dots = true;
-    } else {
+// 10^-place as tinyobjloader forms it: a literal for the first seven places, pow() beyond
+inline double negative_power_of_ten(int place) {
+    static const double literal[8] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+    return place < 8 ? literal[place] : std::pow(10.0, -place);
+}
+
+// Decimal text -> double, NOT through strtod (restates tinyobj::tryParseDouble, tiny_obj_loader.h:836-960, whose results differ
+// from strtod's in the last place): integer digits accumulate as m = m * 10 + d, fraction digits add d * 10^-place, a decimal
+// exponent e gives ldexp(m * 5^e, e).  The scan is greedy -- it stops at the first character that cannot continue the number
+// and keeps what it has -- and fails (leaving *value alone) on: empty text, a first character that is not a sign, digit or
+// point, no integer digit where one is required, an `e` without digits.
+bool scan_decimal(const char* first, const char* last, double* value) {
+    if (first >= last) return false;
+    const char* p = first;
+    bool negative = false, point_first = false;
+    if (*p == '+' || *p == '-') {
+        negative = *p == '-';
+        ++p;
+        point_first = p != last && *p == '.';
+    } else if (*p == '.') {
+        point_first = true;
+    } else if (!is_digit(*p)) {
         return false;
     }
-    end_not_reached = (curr != s_end);
-    if (!leading_decimal_dots) {
-        while (end_not_reached && is_digit(*curr)) {
-            mantissa *= 10;
-            mantissa += static_cast<int>(*curr - 0x30);
-            curr++;
-            read++;
-            end_not_reached = (curr != s_end);
+    double m = 0.0;
+    if (!point_first) {
+        const char* const digits = p;
+        for (; p != last && is_digit(*p); ++p) {
+            m *= 10;
+            m += static_cast<int>(*p - '0');
         }
-        if (read == 0) return false;
+        if (p == digits) return false;
     }
-    if (end_not_reached) {
-        bool has_exp = false;
-        if (*curr == '.') {
-            curr++;
-            read = 1;
-            end_not_reached = (curr != s_end);
-            while (end_not_reached && is_digit(*curr)) {
-                static const double pow_lut[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
-                const int lut_entries = sizeof pow_lut / sizeof pow_lut[0];
-                mantissa += static_cast<int>(*curr - 0x30) * (read < lut_entries ? pow_lut[read] : std::pow(10.0, -read));
-                read++;
-                curr++;
-                end_not_reached = (curr != s_end);
-            }
-            has_exp = end_not_reached;
-        } else if (*curr == 'e' || *curr == 'E') {
-            has_exp = true;
+    int e10 = 0;
+    if (p != last) {
+        bool exponent_may_follow = *p == 'e' || *p == 'E';
+        if (*p == '.') {
+            ++p;
+            for (int place = 1; p != last && is_digit(*p); ++p, ++place) m += static_cast<int>(*p - '0') * negative_power_of_ten(place);
+            exponent_may_follow = p != last;
         }
-        if (has_exp && (*curr == 'e' || *curr == 'E')) {
-            curr++;
-            end_not_reached = (curr != s_end);
-            if (end_not_reached && (*curr == '+' || *curr == '-')) {
-                exp_sign = *curr;
-                curr++;
-            } else if (is_digit(*curr)) {   // (reads *s_end when the token ends in `e': a blank, CR or NUL -- never a digit)
-            } else {
-                return false;   // empty E is not allowed
+        if (exponent_may_follow && (*p == 'e' || *p == 'E')) {
+            ++p;
+            bool exponent_negative = false;
+            if (p != last && (*p == '+' || *p == '-')) {
+                exponent_negative = *p == '-';
+                ++p;
+            } else if (!is_digit(*p)) {   // (at `last` this reads the delimiter behind the token -- a blank, CR or NUL -- like the original)
+                return false;
             }
-            read = 0;
-            end_not_reached = (curr != s_end);
-            while (end_not_reached && is_digit(*curr)) {
-                exponent *= 10;
-                exponent += static_cast<int>(*curr - 0x30);
-                curr++;
-                read++;
-                end_not_reached = (curr != s_end);
+            const char* const digits = p;
+            for (; p != last && is_digit(*p); ++p) {
+                e10 *= 10;
+                e10 += static_cast<int>(*p - '0');
             }
-            exponent *= (exp_sign == '+' ? 1 : -1);
-            if (read == 0) return false;
+            if (exponent_negative) e10 = -e10;
+            if (p == digits) return false;
         }
     }
-    *result = (sign == '+' ? 1 : -1) * (exponent ? std::ldexp(mantissa * std::pow(5.0, exponent), exponent) : mantissa);
+    *value = (negative ? -1 : 1) * (e10 ? std::ldexp(m * std::pow(5.0, e10), e10) : m);
     return true;
 }
 
-// parseReal (tiny_obj_loader.h:962-970)
-float parse_real(const char*& token, double default_value = 0.0) {
+// the next blank-delimited number of a statement as float, `fallback` if it does not parse (restates tinyobj::parseReal,
+// tiny_obj_loader.h:962-970)
+float parse_real(const char*& token, double fallback = 0.0) {
     token += std::strspn(token, " \t");
-    const char* end = token + std::strcspn(token, " \t\r");
-    double val = default_value;
-    try_parse_double(token, end, &val);
-    token = end;
+    const char* const stop = token + std::strcspn(token, " \t\r");
+    double val = fallback;
+    scan_decimal(token, stop, &val);
+    token = stop;
     return static_cast<float>(val);
 }
 
-int pnpoly(int nvert, const float* vertx, const float* verty, float testx, float testy) {
-    int c = 0;
-    for (int i = 0, j = nvert - 1; i < nvert; j = i++)
-        if (((verty[i] > testy) != (verty[j] > testy)) &&
-            (testx < (vertx[j] - vertx[i]) * (testy - verty[i]) / (verty[j] - verty[i]) + vertx[i]))
-            c = !c;
-    return c;
+// Point-in-polygon by crossing number: W. Randolph Franklin's PNPOLY (notice at the top of this file), which tinyobjloader
+// embeds (tiny_obj_loader.h:1350-1362) and uses as its ear test; the comparison and the interpolation are his expression.
+bool inside_polygon(int n, const float* xs, const float* ys, float px, float py) {
+    bool inside = false;
+    int prev = n - 1;
+    for (int i = 0; i < n; prev = i++) {
+        const bool straddles = (ys[i] > py) != (ys[prev] > py);
+        if (straddles && px < (xs[prev] - xs[i]) * (py - ys[i]) / (ys[prev] - ys[i]) + xs[i]) inside = !inside;
+    }
+    return inside;
 }
 
-// tinyobjloader 2.0.0 exportGroupsToShape's polygon path for one face
-void triangulate(const std::vector<Corner>& face, const std::vector<float>& v, std::vector<Corner>& out) {
-    size_t npolys = face.size();
-    if (npolys < 3) return;
-    size_t axes[2] = {1, 2};
-    for (size_t k = 0; k < npolys; ++k) {
-        size_t vi0 = (size_t)face[(k + 0) % npolys].v, vi1 = (size_t)face[(k + 1) % npolys].v, vi2 = (size_t)face[(k + 2) % npolys].v;
-        if ((3 * vi0 + 2) >= v.size() || (3 * vi1 + 2) >= v.size() || (3 * vi2 + 2) >= v.size()) continue;
-        float e0x = v[vi1 * 3] - v[vi0 * 3], e0y = v[vi1 * 3 + 1] - v[vi0 * 3 + 1], e0z = v[vi1 * 3 + 2] - v[vi0 * 3 + 2];
-        float e1x = v[vi2 * 3] - v[vi1 * 3], e1y = v[vi2 * 3 + 1] - v[vi1 * 3 + 1], e1z = v[vi2 * 3 + 2] - v[vi1 * 3 + 2];
-        float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
-        const float eps = std::numeric_limits<float>::epsilon();
-        if (cx > eps || cy > eps || cz > eps) {
-            if (cx > cy && cx > cz) {
-            } else {
-                axes[0] = 0;
-                if (cz > cx && cz > cy) axes[1] = 1;
-            }
-            break;
+// One polygon -> triangles by 2-D ear clipping (restates the polygon branch of tinyobj::exportGroupsToShape, tiny_obj_loader.h:
+// 1365-1600): project on the two axes orthogonal-most to the first non-degenerate corner's normal, take the polygon's winding
+// from its signed area, then cut ears -- a corner whose turn matches the winding and whose triangle holds no other remaining
+// vertex -- starting the search where the last cut was made; give up when a full round finds no ear (the rest is dropped unless
+// exactly a triangle remains).  `xyz` = every vertex parsed so far; corners that point past its end are skipped like there.
+void triangulate_polygon(const std::vector<Corner>& face, const std::vector<float>& xyz, std::vector<Corner>& out) {
+    const size_t n_corners = face.size();
+    if (n_corners < 3) return;
+    const size_t n_floats = xyz.size();
+    auto corner_vertex = [&face, n_corners](size_t k) { return (size_t)face[k % n_corners].v; };
+    // projection plane
+    size_t ax = 1, ay = 2;
+    for (size_t k = 0; k < n_corners; ++k) {
+        const size_t a = corner_vertex(k), b = corner_vertex(k + 1), c = corner_vertex(k + 2);
+        if (3 * a + 2 >= n_floats || 3 * b + 2 >= n_floats || 3 * c + 2 >= n_floats) continue;
+        const float ux = xyz[3 * b] - xyz[3 * a], uy = xyz[3 * b + 1] - xyz[3 * a + 1], uz = xyz[3 * b + 2] - xyz[3 * a + 2];
+        const float wx = xyz[3 * c] - xyz[3 * b], wy = xyz[3 * c + 1] - xyz[3 * b + 1], wz = xyz[3 * c + 2] - xyz[3 * b + 2];
+        const float nx = std::fabs(uy * wz - uz * wy), ny = std::fabs(uz * wx - ux * wz), nz = std::fabs(ux * wy - uy * wx);
+        const float tiny = std::numeric_limits<float>::epsilon();
+        if (!(nx > tiny || ny > tiny || nz > tiny)) continue;
+        if (!(nx > ny && nx > nz)) {   // x-dominant normal: (y, z); z-dominant: (x, y); otherwise (x, z)
+            ax = 0;
+            if (nz > nx && nz > ny) ay = 1;
         }
+        break;
     }
-    float area = 0;
-    for (size_t k = 0; k < npolys; ++k) {
-        size_t vi0 = (size_t)face[(k + 0) % npolys].v, vi1 = (size_t)face[(k + 1) % npolys].v;
-        if ((vi0 * 3 + axes[0]) >= v.size() || (vi0 * 3 + axes[1]) >= v.size() || (vi1 * 3 + axes[0]) >= v.size() ||
-            (vi1 * 3 + axes[1]) >= v.size())
-            continue;
-        float v0x = v[vi0 * 3 + axes[0]], v0y = v[vi0 * 3 + axes[1]], v1x = v[vi1 * 3 + axes[0]], v1y = v[vi1 * 3 + axes[1]];
-        area += (v0x * v1y - v0y * v1x) * 0.5f;
+    // winding
+    float signed_area = 0;
+    for (size_t k = 0; k < n_corners; ++k) {
+        const size_t a = corner_vertex(k), b = corner_vertex(k + 1);
+        if (3 * a + ax >= n_floats || 3 * a + ay >= n_floats || 3 * b + ax >= n_floats || 3 * b + ay >= n_floats) continue;
+        const float x0 = xyz[3 * a + ax], y0 = xyz[3 * a + ay], x1 = xyz[3 * b + ax], y1 = xyz[3 * b + ay];
+        signed_area += (x0 * y1 - y0 * x1) * 0.5f;
     }
-    std::vector<Corner> rem = face;
-    size_t guess = 0;
-    size_t remaining_iterations = face.size();
-    size_t previous_remaining = rem.size();
-    while (rem.size() > 3 && remaining_iterations > 0) {
-        npolys = rem.size();
-        if (guess >= npolys) guess -= npolys;
-        if (previous_remaining != npolys) {
-            previous_remaining = npolys;
-            remaining_iterations = npolys;
+    // ears
+    std::vector<Corner> ring = face;
+    size_t at = 0, tries_left = face.size(), size_seen = ring.size();
+    while (ring.size() > 3 && tries_left > 0) {
+        const size_t n = ring.size();
+        if (at >= n) at -= n;
+        if (size_seen != n) {   // an ear was cut since the last look: a fresh round of tries
+            size_seen = n;
+            tries_left = n;
         } else {
-            remaining_iterations--;
+            --tries_left;
         }
-        Corner ind[3];
-        float vx[3], vy[3];
-        for (size_t k = 0; k < 3; k++) {
-            ind[k] = rem[(guess + k) % npolys];
-            size_t vi = (size_t)ind[k].v;
-            if ((vi * 3 + axes[0]) >= v.size() || (vi * 3 + axes[1]) >= v.size()) {
-                vx[k] = 0.f;
-                vy[k] = 0.f;
-            } else {
-                vx[k] = v[vi * 3 + axes[0]];
-                vy[k] = v[vi * 3 + axes[1]];
-            }
+        Corner tri[3];
+        float tx[3], ty[3];
+        for (size_t k = 0; k < 3; ++k) {
+            tri[k] = ring[(at + k) % n];
+            const size_t v = (size_t)tri[k].v;
+            const bool present = 3 * v + ax < n_floats && 3 * v + ay < n_floats;
+            tx[k] = present ? xyz[3 * v + ax] : 0.f;
+            ty[k] = present ? xyz[3 * v + ay] : 0.f;
         }
-        float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
-        float cross = e0x * e1y - e0y * e1x;
-        if (cross * area < 0.0f) {
-            guess += 1;
+        const float ux = tx[1] - tx[0], uy = ty[1] - ty[0], wx = tx[2] - tx[1], wy = ty[2] - ty[1];
+        const float turn = ux * wy - uy * wx;
+        bool ear = !(turn * signed_area < 0.0f);
+        for (size_t other = 3; ear && other < n; ++other) {
+            const size_t idx = (at + other) % n;
+            if (idx >= ring.size()) continue;
+            const size_t v = (size_t)ring[idx].v;
+            if (3 * v + ax >= n_floats || 3 * v + ay >= n_floats) continue;
+            if (inside_polygon(3, tx, ty, xyz[3 * v + ax], xyz[3 * v + ay])) ear = false;
+        }
+        if (!ear) {
+            ++at;
             continue;
         }
-        bool overlap = false;
-        for (size_t other = 3; other < npolys; ++other) {
-            size_t idx = (guess + other) % npolys;
-            if (idx >= rem.size()) continue;
-            size_t ovi = (size_t)rem[idx].v;
-            if ((ovi * 3 + axes[0]) >= v.size() || (ovi * 3 + axes[1]) >= v.size()) continue;
-            if (pnpoly(3, vx, vy, v[ovi * 3 + axes[0]], v[ovi * 3 + axes[1]])) {
-                overlap = true;
-                break;
-            }
-        }
-        if (overlap) {
-            guess += 1;
-            continue;
-        }
-        out.push_back(ind[0]);
-        out.push_back(ind[1]);
-        out.push_back(ind[2]);
-        size_t removed = (guess + 1) % npolys;
-        while (removed + 1 < npolys) {
-            rem[removed] = rem[removed + 1];
-            removed += 1;
-        }
-        rem.pop_back();
+        out.insert(out.end(), tri, tri + 3);
+        ring.erase(ring.begin() + (std::ptrdiff_t)((at + 1) % n));   // the ear's tip leaves the ring
     }
-    if (rem.size() == 3) {
-        out.push_back(rem[0]);
-        out.push_back(rem[1]);
-        out.push_back(rem[2]);
-    }
+    if (ring.size() == 3) out.insert(out.end(), ring.begin(), ring.end());
 }
 
 thread_local std::string g_obj_error;
@@ -360,7 +372,7 @@ int agpt_obj_parse(const char* text, size_t length, const float* transform16, in
     std::vector<Corner> corners;             // triangulated, all shapes concatenated (trianglemesh.cpp:200-205)
     std::vector<std::vector<Corner>> group;  // PrimGroup::faceGroup: faces waiting for the next flush
     auto flush = [&]() {                     // exportGroupsToShape for the open group
-        for (const std::vector<Corner>& face : group) triangulate(face, v, corners);
+        for (const std::vector<Corner>& face : group) triangulate_polygon(face, v, corners);
         group.clear();
     };
     auto is_space = [](char x) { return x == ' ' || x == '\t'; };
@@ -410,7 +422,7 @@ int agpt_obj_parse(const char* text, size_t length, const float* transform16, in
             std::vector<Corner> face;
             while (!is_new_line(token[0])) {
                 Corner c;
-                if (!parse_triple(token, (int)v.size() / 3, (int)vn.size() / 3, (int)vt.size() / 2, &c)) {
+                if (!read_corner(token, (int)v.size() / 3, (int)vn.size() / 3, (int)vt.size() / 2, &c)) {
                     g_obj_error = std::string("agpt_obj_parse: failed to parse `") + kind + "' line " + std::to_string(lineno) +
                                   " (zero or malformed index)";
                     return AGPT_ERR_INVALID;

@@ -7,9 +7,9 @@ show() { python - "$1" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d['roofline']
-print("value %.1f Mrays/s (%.1f Msamples/s)  ms/step %.1f  trace %.1f (ext %.1f mis %.1f shadow %.1f)  non-trace %.1f" % (
+print("value %.1f Mrays/s (%.1f Msamples/s)  ms/step %.1f  trace %.1f (ext %.1f mis %.1f shadow %.1f)  non-trace %.1f  mean %s" % (
     d['value'], d['config']['msamples_per_s'], d['ms_per_step'], r['trace_ms_per_step'], r['trace_split_ms_per_step']['continuation'],
-    r['trace_split_ms_per_step']['mis'], r['trace_split_ms_per_step']['shadow'], r['render_ms_per_step'] - r['trace_ms_per_step']))
+    r['trace_split_ms_per_step']['mis'], r['trace_split_ms_per_step']['shadow'], r["render_ms_per_step"] - r["trace_ms_per_step"], d["image_mean_rgb"]))
 PY
 }
 for cfg in "$@"; do
