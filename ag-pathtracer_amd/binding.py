@@ -27,7 +27,7 @@ EXPORTS = [
     "agpt_scene_add_plane", "agpt_scene_add_area_light", "agpt_scene_add_uniform_infinite_light", "agpt_scene_add_infinite_area_light",
     "agpt_scene_set_camera",
     "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_toplevel_build", "agpt_toplevel_pack16", "agpt_create_backdrop",
-    "agpt_intersect_batch", "agpt_intersect_device", "agpt_render", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
+    "agpt_intersect_batch", "agpt_intersect_device", "agpt_render", "agpt_li_batch", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
     "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
     "agpt_obj_free", "agpt_obj_last_error", "agpt_write_png", "agpt_write_pfm",
@@ -119,6 +119,7 @@ def lib():
     L.agpt_intersect_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.agpt_intersect_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.agpt_render.argtypes = [vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]
+    L.agpt_li_batch.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.c_int, C.c_int, fp, C.POINTER(C.c_uint32), C.POINTER(Stats)]
     L.agpt_resolve.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     L.agpt_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.agpt_device_free.argtypes = [vp, vp]
@@ -514,6 +515,21 @@ class PathTracer:
         _check(scene.L.agpt_render(scene.h, C.byref(rp), C.c_void_p(int(accum_ptr)), C.byref(st) if want_stats else None),
                "agpt_render")
         return st
+
+    def Li(self, scene, rays, rng_states):
+        """Integrator::Li (integrator.h:28-31, 120-191) for a batch of rays (RAY_DTYPE) with one xorshift32 state each:
+        returns (radiance [n, 3] float32 -- unfiltered --, the states after the paths, stats)."""
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        states = np.ascontiguousarray(rng_states, np.uint32)
+        n = len(rays)
+        assert states.shape == (n,)
+        out = np.zeros((n, 3), np.float32)
+        after = np.zeros(n, np.uint32)
+        st = Stats()
+        u32 = C.POINTER(C.c_uint32)
+        _check(scene.L.agpt_li_batch(scene.h, rays.ctypes.data_as(C.c_void_p), states.ctypes.data_as(u32), n, self.MaxDepth,
+                                     out.ctypes.data_as(C.POINTER(C.c_float)), after.ctypes.data_as(u32), C.byref(st)), "agpt_li_batch")
+        return out, after, st
 
     def render_to_host(self, scene, W, H, spp, **kw):
         """Convenience for tests: allocates a zeroed accumulator, renders, returns (accum[H,W,4], stats)."""

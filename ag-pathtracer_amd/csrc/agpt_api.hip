@@ -709,6 +709,70 @@ static int ensure_pool(agpt_ctx* c, size_t paths, int n_prims) {
     return AGPT_OK;
 }
 
+// The wavefront loop of PathTracer::Li (integrator.h:124-191) over the paths k_generate / k_generate_li have set up in q[0]:
+// per iteration the three trace launches, k_shade and k_resolve_pending.  A path needs at most max_depth + 2 iterations unless it
+// crosses emitter spheres (pass-through re-casts do not count as bounces, integrator.h:152-161): that many run without a host
+// round trip, then the loop keeps going while the active or the resolve queue is non-empty.
+struct WavefrontRun {
+    bool mis_mode, timing, shade_lds_tables, shade_env;
+    int count;              // enable_counters, normalised
+    uint64_t iterations = 0, launches = 0;
+};
+static int run_wavefront(agpt_ctx* c, agpt_scene* s, const RenderConsts& rcn, const PathBuffers& pb, Queues q[2], WavefrontRun& run) {
+    const int count = run.count;
+    const bool mis_mode = run.mis_mode, timing = run.timing;
+    const int shade_grid = c->num_cus * 8;
+    int cur = 0;
+    const int planned = rcn.max_depth + 2;
+    for (int it = 0;; it++) {
+        if (it >= planned) {
+            // (active count and, 4 counters further on, the resolve count)
+            HIP_TRY(hipMemcpyAsync(c->host_pinned, q[cur].counts, (4 * AGPT_QSTRIDE + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->host_pinned[0] == 0 && c->host_pinned[4 * AGPT_QSTRIDE] == 0) break;
+            if (it > 4096) return fail(AGPT_ERR_LIMIT, "agpt: path did not terminate");
+        }
+        const int nxt = cur ^ 1;
+        HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->work.p, 0, 3 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
+        launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
+        if (mis_mode)
+            launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
+        else
+            launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
+        launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+        {
+            const dim3 sg(shade_grid), sb(AGPT_BLOCK);
+            if (run.shade_lds_tables && run.shade_env) hipLaunchKernelGGL((k_shade<true, true>), sg, sb, 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
+            else if (run.shade_lds_tables) hipLaunchKernelGGL((k_shade<true, false>), sg, sb, 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
+            else if (run.shade_env) hipLaunchKernelGGL((k_shade<false, true>), sg, sb, 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
+            else hipLaunchKernelGGL((k_shade<false, false>), sg, sb, 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
+        }
+        // (independent of k_shade: different paths)
+        hipLaunchKernelGGL(k_resolve_pending, dim3(c->num_cus * 8), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur]);
+        cur = nxt;
+        run.iterations++;
+        run.launches += 3;
+    }
+    return AGPT_OK;
+}
+
+static void bind_pool(agpt_ctx* c, PathBuffers& pb, Queues q[2]) {
+    pb.ext_o = c->ext_o.p; pb.ext_d = c->ext_d.p; pb.sh_o = c->sh_o.p; pb.sh_d = c->sh_d.p;
+    pb.mis_o = c->mis_o.p; pb.mis_d = c->mis_d.p; pb.hit = c->hit.p; pb.mis_hit = c->mis_hit.p;
+    pb.occluded = c->occluded.p; pb.mis_ok = c->mis_ok.p; pb.beta4 = c->beta4.p; pb.L4 = c->L4.p; pb.fac4 = c->fac4.p;
+    pb.c1 = c->c1.p; pb.c2 = c->c2.p;
+    for (int i = 0; i < 2; i++) {
+        q[i].active = c->q[i][0].p; q[i].ext = c->q[i][1].p; q[i].mis = c->q[i][2].p; q[i].shadow = c->q[i][3].p;
+        q[i].resolve = c->q[i][4].p;
+        q[i].counts = c->qcounts.p + AGPT_NQUEUES * AGPT_QSTRIDE * i;
+    }
+}
+static bool shade_tables_fit_lds(const DevScene& d) {
+    return d.n_prims <= AGPT_SHADE_LDS_PRIMS && d.n_materials <= AGPT_SHADE_LDS_MATERIALS && d.n_lights <= AGPT_SHADE_LDS_LIGHTS &&
+           !getenv("AGPT_SHADE_GLOBAL_TABLES");
+}
+
 static void read_counters(const DevCounters& d, agpt_stats* st) {
     st->closest_rays = d.closest_rays;
     st->anyhit_rays = d.anyhit_rays;
@@ -827,27 +891,19 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     s->dev.cam = s->cam;
 
     PathBuffers pb;
-    pb.ext_o = c->ext_o.p; pb.ext_d = c->ext_d.p; pb.sh_o = c->sh_o.p; pb.sh_d = c->sh_d.p;
-    pb.mis_o = c->mis_o.p; pb.mis_d = c->mis_d.p; pb.hit = c->hit.p; pb.mis_hit = c->mis_hit.p;
-    pb.occluded = c->occluded.p; pb.mis_ok = c->mis_ok.p; pb.beta4 = c->beta4.p; pb.L4 = c->L4.p; pb.fac4 = c->fac4.p;
-    pb.c1 = c->c1.p; pb.c2 = c->c2.p;
     Queues q[2];
-    for (int i = 0; i < 2; i++) {
-        q[i].active = c->q[i][0].p; q[i].ext = c->q[i][1].p; q[i].mis = c->q[i][2].p; q[i].shadow = c->q[i][3].p;
-        q[i].resolve = c->q[i][4].p;
-        q[i].counts = c->qcounts.p + AGPT_NQUEUES * AGPT_QSTRIDE * i;
-    }
-    const int count = rp->enable_counters == 2 ? 2 : (rp->enable_counters != 0 ? 1 : 0);
-    const bool mis_mode = use_fast_trace(c, s->dev, count) && !c->mis_closest;
-    const bool timing = rp->enable_timing != 0 && stats != nullptr;
+    bind_pool(c, pb, q);
+    WavefrontRun run;
+    run.count = rp->enable_counters == 2 ? 2 : (rp->enable_counters != 0 ? 1 : 0);
+    run.mis_mode = use_fast_trace(c, s->dev, run.count) && !c->mis_closest;
+    run.timing = rp->enable_timing != 0 && stats != nullptr;
+    run.shade_lds_tables = shade_tables_fit_lds(s->dev);
+    run.shade_env = !s->envs.empty();   // an InfiniteAreaLight is present
+    const bool timing = run.timing;
     c->tev_used = 0;
     c->tev_kind.clear();
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    uint64_t iterations = 0, launches = 0;
-    const int shade_grid = c->num_cus * 8;
-    const bool shade_lds_tables = s->dev.n_prims <= AGPT_SHADE_LDS_PRIMS && s->dev.n_materials <= AGPT_SHADE_LDS_MATERIALS &&
-                                  s->dev.n_lights <= AGPT_SHADE_LDS_LIGHTS && !getenv("AGPT_SHADE_GLOBAL_TABLES");
 
     for (int s0 = rp->spp_begin; s0 < rp->spp_begin + rp->spp_count; s0 += S) {
         RenderConsts rcn;
@@ -855,43 +911,15 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         rcn.s0 = s0; rcn.S = std::min(S, rp->spp_begin + rp->spp_count - s0);
         rcn.seed_base = rp->seed_base; rcn.max_depth = rp->max_depth;
         rcn.accum_pitch = rp->accum_pitch; rcn.accum_row0 = rp->accum_row0; rcn.NP = NP;
-        rcn.mis_mode = mis_mode ? 1 : 0;
-        rcn.answer_rays = (mis_mode && !rp->trace_all_rays) ? 1 : 0;
+        rcn.mis_mode = run.mis_mode ? 1 : 0;
+        rcn.answer_rays = (run.mis_mode && !rp->trace_all_rays) ? 1 : 0;
         rcn.il_block = rp->interleave_block; rcn.il_world = rp->interleave_world; rcn.il_rank = rp->interleave_rank;
         const uint32_t total = NP * (uint32_t)rcn.S;
-        int cur = 0;
         hipLaunchKernelGGL(k_generate, dim3((total + AGPT_BLOCK - 1) / AGPT_BLOCK), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb,
-                           q[cur]);
-        // a path needs at most max_depth+2 iterations unless it crosses emitter spheres (pass-through re-casts do
-        // not count as bounces); run that many, then keep going while the active queue is non-empty
-        int planned = rp->max_depth + 2;
-        for (int it = 0;; it++) {
-            if (it >= planned) {
-                // (active count and, 4 counters further on, the resolve count)
-                HIP_TRY(hipMemcpyAsync(c->host_pinned, q[cur].counts, (4 * AGPT_QSTRIDE + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                       c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                if (c->host_pinned[0] == 0 && c->host_pinned[4 * AGPT_QSTRIDE] == 0) break;
-                if (it > 4096) return fail(AGPT_ERR_LIMIT, "agpt_render: path did not terminate");
-            }
-            const int nxt = cur ^ 1;
-            HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
-            HIP_TRY(hipMemsetAsync(c->work.p, 0, 3 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
-            launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
-            if (mis_mode)
-                launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
-            else
-                launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
-            launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
-            if (shade_lds_tables)
-                hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
-            else
-                hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
-            // (independent of k_shade: different paths)
-            hipLaunchKernelGGL(k_resolve_pending, dim3(c->num_cus * 8), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur]);
-            cur = nxt;
-            iterations++;
-            launches += 3;
+                           q[0]);
+        {
+            const int rc_run = run_wavefront(c, s, rcn, pb, q, run);
+            if (rc_run) return rc_run;
         }
         hipLaunchKernelGGL(k_accumulate, dim3((NP + AGPT_BLOCK - 1) / AGPT_BLOCK), dim3(AGPT_BLOCK), 0, c->stream, rcn, pb,
                            (float4*)accum_dev, c->counters.p);
@@ -943,8 +971,8 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
         }
 #endif
         stats->samples = (uint64_t)NP * (uint64_t)rp->spp_count;
-        stats->iterations = iterations;
-        stats->trace_launches = launches;
+        stats->iterations = run.iterations;
+        stats->trace_launches = run.launches;
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         stats->total_ms = ms;
@@ -959,6 +987,66 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
                 else stats->shadow_ms += t;
             }
         }
+    }
+    return AGPT_OK;
+}
+
+int agpt_li_batch(agpt_scene* s, const agpt_ray* rays, const uint32_t* rng_states, int n, int max_depth, float* radiance3_out,
+                  uint32_t* rng_states_out, agpt_stats* stats) {
+    if (!s || !rays || !rng_states || !radiance3_out || n < 0 || max_depth < 0 || max_depth > 200)
+        return fail(AGPT_ERR_INVALID, "agpt_li_batch: bad argument");
+    if (!s->committed) return fail(AGPT_ERR_INVALID, "agpt_li_batch: scene not committed");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (n == 0) return AGPT_OK;
+    agpt_ctx* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    TempBuf<agpt_ray> d_rays;
+    TempBuf<uint32_t> d_rng;
+    TempBuf<float> d_out;
+    if (d_rays.alloc((size_t)n) != hipSuccess || d_rng.alloc((size_t)n) != hipSuccess || d_out.alloc(3 * (size_t)n) != hipSuccess)
+        return fail(AGPT_ERR_NOMEM, "agpt_li_batch: out of device memory");
+    HIP_TRY(hipMemcpyAsync(d_rays.p, rays, (size_t)n * sizeof(agpt_ray), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_rng.p, rng_states, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    int rc = ensure_pool(c, (size_t)n, s->dev.n_prims);
+    if (rc) return rc;
+    PathBuffers pb;
+    Queues q[2];
+    bind_pool(c, pb, q);
+    WavefrontRun run;
+    run.count = 0;
+    run.mis_mode = use_fast_trace(c, s->dev, 0) && !c->mis_closest;
+    run.timing = false;
+    run.shade_lds_tables = shade_tables_fit_lds(s->dev);
+    run.shade_env = !s->envs.empty();
+    RenderConsts rcn{};
+    rcn.max_depth = max_depth;
+    rcn.mis_mode = run.mis_mode ? 1 : 0;
+    rcn.answer_rays = run.mis_mode ? 1 : 0;
+    c->tev_used = 0;
+    c->tev_kind.clear();
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    const dim3 grid((unsigned)((n + AGPT_BLOCK - 1) / AGPT_BLOCK)), block(AGPT_BLOCK);
+    hipLaunchKernelGGL(k_generate_li, grid, block, 0, c->stream, (const agpt_ray*)d_rays.p, (const uint32_t*)d_rng.p, (uint32_t)n, pb, q[0]);
+    rc = run_wavefront(c, s, rcn, pb, q, run);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_export_li, grid, block, 0, c->stream, pb, (uint32_t)n, d_out.p, rng_states_out ? d_rng.p : (uint32_t*)nullptr);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(c->take_deferred());
+    HIP_TRY(hipMemcpyAsync(radiance3_out, d_out.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (rng_states_out) HIP_TRY(hipMemcpyAsync(rng_states_out, d_rng.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stats) {
+        DevCounters dc;
+        HIP_TRY(hipMemcpy(&dc, c->counters.p, sizeof(dc), hipMemcpyDeviceToHost));
+        read_counters(dc, stats);
+        stats->samples = (uint64_t)n;
+        stats->iterations = run.iterations;
+        stats->trace_launches = run.launches;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        stats->total_ms = ms;
     }
     return AGPT_OK;
 }

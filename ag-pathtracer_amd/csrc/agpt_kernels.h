@@ -254,48 +254,12 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
     constexpr int BLOCK = AGPT_BLOCK;
-#ifdef AGPT_X_STAGED
-    constexpr bool STAGED = true;
-#else
-    constexpr bool STAGED = false;
-#endif
-    // the primitive records live in LDS for short lists unless the LDS is needed for the staged pair fetch
-    constexpr bool PRIM_LDS = !LIST && !STAGED;
+    constexpr bool PRIM_LDS = !LIST;   // short lists: the primitive records live in LDS
     __shared__ uint32_t s_stack[DEPTH * BLOCK];
     __shared__ float4 s_prim[PRIM_LDS ? 2 * 64 : 2];
-    // STAGED: an interior step fetches its 64-byte pair records QUAD-COOPERATIVELY through LDS-DMA: instruction j (0..3) makes
-    // the four lanes of every quad read the four 16-byte quarters of the record of the quad's lane j -- 64 contiguous bytes per
-    // quad and instruction, which the vector L1 serves as one request -- straight into row j of the wave's staging buffer; each
-    // lane then reads its own record back with 4 ds_read_b128.  (Rows padded by 16 bytes: conflict-free reads.)
-    __shared__ float4 s_stage[STAGED ? BLOCK / 64 : 1][4][STAGED ? 65 : 1];
     uint32_t* stack = s_stack + threadIdx.x;
     uint32_t* spill_col = SPILL ? spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
     const size_t spill_stride = (size_t)gridDim.x * BLOCK;
-#ifdef AGPT_STACK_RING
-    // The LDS part of a deep stack is a RING of the DEPTH newest entries: a push onto a full ring first moves the OLDEST entry it
-    // holds to the lane's HBM column, a pop below the ring's bottom reads that column.  The entries a descent pushes and pops
-    // next stay in LDS whatever the depth; only a lane that unwinds past DEPTH pending entries touches HBM.  (The round-2
-    // layout kept entries 0 .. DEPTH-1 in LDS and sent the TOP of a deep stack -- the entries in use -- to HBM.)
-    static_assert(!SPILL || (DEPTH & (DEPTH - 1)) == 0, "ring stack: DEPTH must be a power of two");
-    int slo = 0;   // lowest stack index the ring holds (entries below it are in the HBM column)
-    auto stack_push = [&](int k, uint32_t v) {
-        if (SPILL) {
-            if (k - slo == DEPTH) {
-                spill_col[(size_t)slo * spill_stride] = stack[(slo & (DEPTH - 1)) * BLOCK];
-                slo++;
-            }
-            stack[(k & (DEPTH - 1)) * BLOCK] = v;
-        } else {
-            stack[k * BLOCK] = v;
-        }
-    };
-    auto stack_at = [&](int k) -> uint32_t {
-        if (!SPILL) return stack[k * BLOCK];
-        if (k >= slo) return stack[(k & (DEPTH - 1)) * BLOCK];
-        slo = k;
-        return spill_col[(size_t)k * spill_stride];
-    };
-#else
     auto stack_push = [&](int k, uint32_t v) {
         if (!SPILL || k < DEPTH)
             stack[k * BLOCK] = v;
@@ -306,7 +270,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         if (!SPILL || k < DEPTH) return stack[k * BLOCK];
         return spill_col[(size_t)(k - DEPTH) * spill_stride];
     };
-#endif
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // (a value loaded through a pointer counts as divergent for the compiler: readfirstlane keeps the bookkeeping scalar)
@@ -424,9 +387,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
        uint32_t ts_push[5] = {0, 0, 0, 0, 0};)
     TCK(unsigned long long tk_refill = 0, tk_vote = 0, tk_bmem = 0, tk_balu = 0, tk_c = 0, tk_a = 0; const unsigned long long tk_begin = TCK_NOW();)
 
-#if defined(AGPT_X_DUMMYLOAD) || defined(AGPT_X_PF_CHILDREN) || defined(AGPT_X_PF_LEAF)
-    float x_pf0 = 0.f, x_pf1 = 0.f;   // developer experiments (tools/build_variant.py): registers of touch loads
-#endif
     uint32_t pfa_off = 0;       // lane 0: offset returned by the pending frontier atomic (stage A)
     uint32_t pfa_seg = 0;
     bool pfa_valid = false;     // wave-uniform, like every *_valid / *_n below
@@ -631,9 +591,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     hb1 = 0.f;
                     hb2 = 0.f;
                     sp = 0;
-#ifdef AGPT_STACK_RING
-                    slo = 0;
-#endif
                     cur = pick_next(mask);
                 }
             }
@@ -661,102 +618,24 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             TS(ts_act += (unsigned long long)n_active; if (!(nB >= nA && nB >= nC) && !(nC >= nA)) { ts_steps[0]++; ts_lanes[0] += nA; })
             if (nB >= nA && nB >= nC) {
                 TS(ts_steps[1]++; ts_lanes[1] += nB;)
-                if (STAGED) {
-                    // (all 64 lanes run this: a lane fetches quarters of its quad-mates' records whatever its own state is)
-                    const unsigned long long bm = __ballot(cur < CUR_B_END);
-                    float4* stage = &s_stage[threadIdx.x >> 6][0][0];
-                    if (MODE != 1) __builtin_amdgcn_s_setprio(1);
-                    // quads whose lane j is at an interior node; all four lanes of such a quad take part
-#if defined(__HIP_DEVICE_COMPILE__)
-#define AGPT_STAGE_STEP(j)                                                                                                  \
-    {                                                                                                                       \
-        unsigned long long qj = (bm >> (j)) & 0x1111111111111111ull;                                                        \
-        qj |= qj << 1;                                                                                                      \
-        qj |= qj << 2;                                                                                                      \
-        const uint32_t cj = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, (j) * 0x55, 0xF, 0xF, true); /* quad_perm [j,j,j,j] */ \
-        if ((qj >> lane) & 1ull) __builtin_amdgcn_global_load_lds(sc.nodes + 2 * (size_t)cj + (lane & 3), stage + 65 * (j), 16, 0, 0); \
-    }
-                    AGPT_STAGE_STEP(0)
-                    AGPT_STAGE_STEP(1)
-                    AGPT_STAGE_STEP(2)
-                    AGPT_STAGE_STEP(3)
-#undef AGPT_STAGE_STEP
-#endif
-                    if (MODE != 1) {
-                        asm volatile("" ::: "memory");
-                        __builtin_amdgcn_s_setprio(0);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
                 if (cur < CUR_B_END) {
                     // the wave is about to wait for these loads whatever happens: let its issue win the arbitration against
                     // waves in the middle of their arithmetic (-1.5 ms per C3 step on the closest-hit and MIS launches; the
                     // short any-hit steps lose 0.3 ms with it)
-                    if (MODE != 1 && !STAGED) __builtin_amdgcn_s_setprio(1);
-#ifdef AGPT_X_STAGED
-                    NodePair np;
-                    {   // the lane's record: row (lane & 3), slots 4 * quad .. 4 * quad + 3
-                        const float4* mine = &s_stage[threadIdx.x >> 6][lane & 3][lane & ~3];
-                        np.n0 = mine[0];
-                        np.n1 = mine[1];
-                        np.n2 = mine[2];
-                        np.n3 = mine[3];
-                    }
-#elif defined(AGPT_X_ROOT_LDS)
-                    // root pairs (a mesh's root-box test, 11 % of the interior steps) come from the LDS copy of the primitive
-                    // records instead of through the vector L1
-                    NodePair np;
-                    if (LIST || cur < rootpair_base) {
-                        np = load_pair(sc, cur);
-                    } else {
-                        const uint32_t rk = (cur - rootpair_base) >> 1;
-                        const float4 ra = s_prim[2 * rk], rb = s_prim[2 * rk + 1];
-                        np.n0.x = ra.x; np.n0.y = ra.x; np.n0.z = ra.y; np.n0.w = ra.y;
-                        np.n1.x = ra.z; np.n1.y = ra.z; np.n1.z = rb.x; np.n1.w = rb.x;
-                        np.n2.x = rb.y; np.n2.y = rb.y; np.n2.z = rb.z; np.n2.w = rb.z;
-                        np.n3.x = rb.w; np.n3.y = rb.w; np.n3.z = 0.f; np.n3.w = 0.f;
-                    }
-#else
+                    if (MODE != 1) __builtin_amdgcn_s_setprio(1);
                     const NodePair np = load_pair(sc, cur);
-#endif
-#ifndef AGPT_X_STAGED
-#ifdef AGPT_X_DUMMYLOAD
-                    {   // one more lookup of the same line (plain cached load through a laundered pointer)
-                        // (inline asm: its own destination register, no interaction with the compiler's waitcnt bookkeeping; the
-                        // compiler's vmcnt(0) for the pair record covers it, loads return in order)
-                        asm volatile("global_load_dword v95, %0, off offset:60" : : "v"(sc.nodes + 2 * (size_t)cur) : "memory", "v95");
-                    }
-#endif
                     if (MODE != 1) {
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_s_setprio(0);
                     }
-#endif
                     TCK(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk_bmem += TCK_NOW() - tk_v1;)
                     float dl, dr;
                     bool hl, hr;
                     const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
-#ifdef AGPT_X_PF_CHILDREN
-                    {   // touch the first line of both children's records while the slab arithmetic runs (after the whole record has
-                        // arrived: the touches are younger than it, and a wait for the record would wait for them too)
-                        asm volatile("" ::"v"(np.n0.x), "v"(np.n1.x), "v"(np.n2.x), "v"(np.n3.x));
-                        auto touch = [&](uint32_t enc) -> float {
-                            // interior children only (leaf children: AGPT_X_PF_LEAF); a leaf child re-touches this record
-                            const uint32_t k = (int32_t)enc < 0 ? cur : enc;
-                            asm volatile("global_load_dword v95, %0, off" : : "v"(sc.nodes + 2 * (size_t)k) : "memory", "v95");
-                            return 0.f;
-                        };
-                        x_pf0 = touch(encl);
-                        x_pf1 = touch(cur < rootpair_base ? encr : encl);
-                    }
-#endif
                     pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
                     if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
                         if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
                     }
-#ifdef AGPT_X_DUMMYLOAD
-                    asm volatile("" ::"v"(x_pf0));
-#endif
                     if (COUNT) {
                         if (cur < rootpair_base) c_int++; else c_root++;
                     }
@@ -777,13 +656,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         sp--;
                         cur = stack_at(sp);
                     }
-#ifdef AGPT_X_PF_LEAF
-                    // the lane has arrived at a leaf and will wait for the wave's next leaf step: start fetching its first triangle
-                    if ((int32_t)cur < 0 && (cur & AGPT_ENC_BIGLEAF) != AGPT_ENC_BIGLEAF) {
-                        const float4* tpf = sc.tri_verts + 3 * (size_t)(cur & 0x0FFFFFFFu);
-                        asm volatile("global_load_dword v94, %0, off\n\tglobal_load_dword v94, %0, off offset:44" : : "v"(tpf) : "memory", "v94");
-                    }
-#endif
                 }
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_balu += TCK_NOW() - tk_v1;)
             } else if (nC >= nA) {
@@ -795,9 +667,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     for (uint32_t i = 0; i < cnt; ++i) {
                         const float4* tp = sc.tri_verts + 3 * (size_t)(first + i);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
-#ifdef AGPT_X_PF_LEAF
-                        asm volatile("" ::"v"(x_pf0), "v"(x_pf1), "v"(a.x));
-#endif
                         const v3 q0 = V3(a.x, a.y, a.z), q1 = V3(b.x, b.y, b.z), q2 = V3(c.x, c.y, c.z);
                         const uint32_t q_id = __float_as_uint(a.w), q_flags = __float_as_uint(b.w);
                         float t, b1, b2;
@@ -1121,6 +990,45 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
     }
 }
 
+// agpt_li_batch: Integrator::Li(ray, scene) (integrator.h:28-31) for n caller-supplied rays, each with its own RandomFloat() stream
+// (an xorshift32 state, template/template.cpp:667-675).  The Ray ctor normalises D (camera.h:6); ray.t is the caller's tmax.
+__global__ void __launch_bounds__(AGPT_BLOCK)
+k_generate_li(const agpt_ray* __restrict__ rays, const uint32_t* __restrict__ rng_states, uint32_t n, PathBuffers pb, Queues q) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const agpt_ray r = rays[i];
+    const v3 d = normalize(V3(r.d[0], r.d[1], r.d[2]));
+    float4 o4, d4, b4, l4;
+    o4.x = r.o[0]; o4.y = r.o[1]; o4.z = r.o[2]; o4.w = r.tmax;
+    d4.x = d.x; d4.y = d.y; d4.z = d.z; d4.w = 0.f;
+    b4.x = 1.f; b4.y = 1.f; b4.z = 1.f; b4.w = __uint_as_float(0u);
+    l4.x = 0.f; l4.y = 0.f; l4.z = 0.f; l4.w = __uint_as_float(rng_states[i]);
+    pb.ext_o[i] = o4;
+    pb.ext_d[i] = d4;
+    pb.beta4[i] = b4;
+    pb.L4[i] = l4;
+    q.active[i] = i;
+    q.ext[i] = i;
+    if (i == 0) {
+        QCOUNT(q, 0) = n;
+        QCOUNT(q, 1) = n;
+        QCOUNT(q, 2) = 0;
+        QCOUNT(q, 3) = 0;
+        QCOUNT(q, 4) = 0;
+    }
+}
+// Li's return value as it is (the NaN / inf filter belongs to MyApp::Tick, myapp.cpp:169-172, not to the integrator) and the
+// stream's state after the path, so that a host can go on drawing from it
+__global__ void k_export_li(PathBuffers pb, uint32_t n, float* __restrict__ radiance3, uint32_t* __restrict__ rng_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 l4 = pb.L4[i];
+    radiance3[3 * i] = l4.x;
+    radiance3[3 * i + 1] = l4.y;
+    radiance3[3 * i + 2] = l4.z;
+    if (rng_out) rng_out[i] = __float_as_uint(l4.w);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // PathTracer::Li's loop body (integrator.h:132-188) in wavefront form, for one path.  Returns which of the next
 // iteration's queues the path goes to.
@@ -1173,6 +1081,10 @@ __device__ __forceinline__ v3 pending_light_sample(const DevScene& sc, const Ren
 #define SCK_ARGS
 #define SCK(k)
 #endif
+// ENV: the scene has an InfiniteAreaLight (lights.cpp:31-112).  Its sampling / pdf / Le helpers are out-of-line calls whose mere
+// presence costs the register allocation of every path (values live across a call site go to callee-saved registers); scenes
+// without an environment map -- every BASELINE configuration -- run the instantiation that does not contain them.
+template <bool ENV>
 __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderConsts& rc, const PathBuffers& pb, uint32_t pid SCK_PARAMS) {
     uint32_t bits = 0;
     // Every per-path record is fetched up front, unconditionally: the loads then overlap in one memory round trip instead
@@ -1224,7 +1136,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                 for (int li = 0; li < sc.n_lights; li++) {
                     if (sc.lights[li].type == AGPT_LIGHT_UNIFORM_INFINITE)
                         L = L + beta * mat_v3(sc.lights[li].L);
-                    else if (sc.lights[li].type == AGPT_LIGHT_INFINITE_AREA)
+                    else if (ENV && sc.lights[li].type == AGPT_LIGHT_INFINITE_AREA)
                         L = L + beta * env_Le(&sc.envs[sc.lights[li].env], D);
                 }
             }
@@ -1277,7 +1189,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                     visD = normalize(wi);
                     visT = AGPT_FLT_MAX;
                     Li = mat_v3(light.L);
-                } else if (light.type == AGPT_LIGHT_INFINITE_AREA) {  // lights.cpp:50-90: 1 extra draw, offset along n
+                } else if (ENV && light.type == AGPT_LIGHT_INFINITE_AREA) {  // lights.cpp:50-90: 1 extra draw, offset along n
                     const DevEnv& env = sc.envs[light.env];
                     Li = V3s(0.f);
                     if (env_sample_li(&env, rng_float(rng), &wi, &lightPdf)) {
@@ -1398,14 +1310,14 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                         float lp;
                         if (light.type == AGPT_LIGHT_UNIFORM_INFINITE)
                             lp = dot(s.n, wi) > 0 ? AGPT_INV2PI : 0.f;  // lights.cpp:26-28 (geometric n)
-                        else if (light.type == AGPT_LIGHT_INFINITE_AREA)
+                        else if (ENV && light.type == AGPT_LIGHT_INFINITE_AREA)
                             lp = env_pdf_li(&sc.envs[light.env], wi);
                         else
                             lp = sphere_pdf(sc.prims[light.shape], s.p);
                         if (lp != 0) {
                             float weight = power_heuristic(1, pdf, 1, lp);
                             // Le(-wi) of the light's shape, or light.Le(ray) on a miss (ray.D = normalize(wi))
-                            v3 Li2 = light.type == AGPT_LIGHT_INFINITE_AREA ? env_Le(&sc.envs[light.env], normalize(wi))
+                            v3 Li2 = ENV && light.type == AGPT_LIGHT_INFINITE_AREA ? env_Le(&sc.envs[light.env], normalize(wi))
                                                                             : mat_v3(light.L);
                             // the reference traces this ray before it looks at Li (integrator.h:77-88); a black Li only
                             // means nothing is added afterwards
@@ -1515,7 +1427,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 #define AGPT_SHADE_LDS_PRIMS 256
 #define AGPT_SHADE_LDS_MATERIALS 128
 #define AGPT_SHADE_LDS_LIGHTS 64
-template <bool LDS_TABLES>
+template <bool LDS_TABLES, bool ENV>
 __global__ void __launch_bounds__(AGPT_BLOCK, AGPT_SHADE_WAVES)
 k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout, DevCounters* __restrict__ counters) {
     __shared__ DevPrim s_tab_prims[LDS_TABLES ? AGPT_SHADE_LDS_PRIMS : 1];
@@ -1565,7 +1477,7 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
             uint32_t pid = 0, bits = 0;
             if (qi < n_active) {
                 pid = qin.active[qi];
-                bits = shade_path(sc, rc, pb, pid SCK_ARGS);
+                bits = shade_path<ENV>(sc, rc, pb, pid SCK_ARGS);
             }
             s_pid[u][tid] = pid;     // (slots private to the thread: no synchronisation)
             s_bits[u][tid] = bits;

@@ -102,14 +102,7 @@ __device__ __forceinline__ NodePair load_pair(const DevScene& sc, uint32_t left)
     p.n0 = np[0];
     p.n1 = np[1];
     p.n2 = np[2];
-#ifdef AGPT_X_N3_X2
-    {   // only the two child encodings of the fourth quarter are used: fetch 8 bytes instead of 16
-        const float2 e = *reinterpret_cast<const float2*>(np + 3);
-        p.n3.x = e.x; p.n3.y = e.y; p.n3.z = 0.f; p.n3.w = 0.f;
-    }
-#else
     p.n3 = np[3];
-#endif
     return p;
 }
 __device__ __forceinline__ void pair_boxes_fast(const NodePair& p, const TraceRay& r, float rayt, bool& hl, bool& hr,

@@ -48,6 +48,10 @@ int main(int argc, char** argv) {
         agpt_ray pick{{-1.46f, 1.16f, -4.64f}, {1.46f, -1.16f, 4.64f}, 3.402823466e+38f};
         agpt_hit hit;
         if (scene.Intersect(pick, hit)) std::printf("pick: prim=%d t=%.6f\n", hit.prim, hit.t);
+        // one Integrator::Li call on that ray, drawing from the reference's global stream (seed: template/template.cpp:667)
+        uint32_t random_state = 0x12345678u;
+        const float3 L = integrator.Li(scene, pick, random_state);
+        std::printf("li: %.9g %.9g %.9g state=0x%08x\n", L.x, L.y, L.z, random_state);
     } catch (const Error& e) {
         std::fprintf(stderr, "agpt error %d: %s\n", e.code, e.what());
         return 1;

@@ -207,6 +207,16 @@ int agpt_intersect_device(agpt_scene*, const agpt_ray* rays_dev, int n, agpt_hit
  * has been enqueued and, if stats != NULL, synchronised. */
 int agpt_render(agpt_scene*, const agpt_render_params*, float* accum_dev, agpt_stats* stats);
 
+/* Integrator::Li(const Ray&, const Scene&) (integrator.h:28-31) of PathTracer (integrator.h:120-191) for n rays of the caller --
+ * the single-ray entry the reference's split-screen compare (myapp.cpp:168) and mouse picking (myapp.cpp:197-201) use, batched.
+ * rays / rng_states / radiance3_out are HOST arrays.  rng_states[i] is the xorshift32 state the path's RandomFloat() calls start
+ * from (template/template.cpp:667-675; the reference has one global state -- a host that wants one stream per ray derives them
+ * as agpt_render does: WangHash((pixel + W*H*sample + 1)*17 + seed_base)); rng_states_out (may be NULL) receives the state after
+ * the path.  radiance3_out[3i..3i+2] is Li's return value unfiltered (the NaN / inf reject belongs to the caller's loop,
+ * myapp.cpp:169-172).  Ray::t = rays[i].tmax; the direction is normalised like Ray's ctor. */
+int agpt_li_batch(agpt_scene*, const agpt_ray* rays, const uint32_t* rng_states, int n, int max_depth, float* radiance3_out,
+                  uint32_t* rng_states_out, agpt_stats* stats);
+
 /* ---- multi-GPU (one process / context per GPU) -----------------------------------------------------------
  * The reference is single-process (myapp.cpp:163-175 is its whole frame loop); a multi-GPU host splits the film into
  * row blocks dealt round-robin to the ranks (agpt_render_params::interleave_*), every rank accumulates its blocks for

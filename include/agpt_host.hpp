@@ -358,6 +358,20 @@ public:
         acc.AddSamples(spp);
         return st;
     }
+    // Integrator::Li(const Ray&, const Scene&) (integrator.h:28-31) for n rays -- what MyApp::Tick calls per pixel (myapp.cpp:168)
+    // and the mouse-pick overlay per click (myapp.cpp:197-201).  rng[i] is the RandomFloat() state path i starts from and receives
+    // the state it ends with (the reference keeps ONE such state, template/template.cpp:667: pass it for a single ray and store it
+    // back to continue its stream).  radiance[i] is Li's return value, unfiltered.
+    void Li(Scene& scene, const agpt_ray* rays, uint32_t* rng, int n, float3* radiance) const {
+        std::vector<float> out(3 * (size_t)n);
+        check(agpt_li_batch(scene.handle(), rays, rng, n, MaxDepth, out.data(), rng, nullptr), "agpt_li_batch");
+        for (int i = 0; i < n; i++) radiance[i] = float3{out[3 * i], out[3 * i + 1], out[3 * i + 2]};
+    }
+    float3 Li(Scene& scene, const agpt_ray& ray, uint32_t& rng) const {
+        float3 L{0.f, 0.f, 0.f};
+        Li(scene, &ray, &rng, 1, &L);
+        return L;
+    }
     int MaxDepth;
 };
 

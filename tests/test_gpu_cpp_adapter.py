@@ -54,6 +54,20 @@ def test_cpp_example_matches_oracle(tmp_path):
     # powf(x, 2.2f) of the floor colour is computed by libm in C++ and by numpy here: allow 1e-5 relative
     assert np.allclose(got, mean, rtol=1e-5), (got, mean)
     assert abs(int(m.group(1)) - st.rays) <= 1e-4 * st.rays
+    # PathTracer::Li on the pick ray (agpt_li_batch through the adapter), stream seeded like the reference's global RNG
+    ml = re.search(r"li: (\S+) (\S+) (\S+) state=0x([0-9a-f]+)", out)
+    assert ml, out
+    ray = np.zeros(1, ag.RAY_DTYPE)
+    ray["o"] = [-1.46, 1.16, -4.64]
+    ray["d"] = [1.46, -1.16, 4.64]
+    ray["tmax"] = 3.402823466e+38
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        L, state, _ = o.li(ray[0], 0x12345678)
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    assert np.allclose(np.float32([float(ml.group(i)) for i in (1, 2, 3)]), L, rtol=2e-5), (ml.groups(), L)
+    assert int(ml.group(4), 16) == state
 
 
 def write_obj(path, v, n, idx):
