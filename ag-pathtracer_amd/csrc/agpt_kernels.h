@@ -200,7 +200,7 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 
 // ---------------------------------------------------------------------------------------------------------
 // Production trace kernel (the generic k_trace above stays as the instrumented variant and the fallback for more than
-// 512 primitives; both are checked against the oracle and against each other).  Same decisions as trace_scene(),
+// 1024 primitives; both are checked against the oracle and against each other).  Same decisions as trace_scene(),
 // restructured for wave efficiency on 64-wide CDNA4 wavefronts:
 //   * persistent waves with IN-FLIGHT REFILL: when at least AGPT_REFILL lanes have retired their rays the wave hands
 //     them new rays from a wave-private LDS ring instead of idling until all 64 are done;
@@ -226,8 +226,6 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 //     root_P < t_s when P precedes S in Scene::primitives and root_P <= t_s when it follows (Sphere::Intersect accepts
 //     root <= ray.t, so a tie goes to the later primitive); degenerate triangles never block (quirk 11).
 // Every MIS ray is still traced through the BVH; it stops at the first blocker instead of finishing a closest-hit search.
-// DEPTH: per-lane stack entries in LDS -- AGPT_STACK_DEPTH (32 KiB/block, 4 blocks per CU) for the usual trees,
-// AGPT_STACK_DEPTH_MAX (64 KiB/block, 2 blocks per CU) for BVHs deeper than that
 // LIST: scenes with more than 64 primitives.  k_candidates (below) has walked the top-level tree over the meshes' root
 // boxes once per ray and left one 64-bit candidate word per chunk of 64 primitives plus a word saying which chunks have
 // any (cand_mask[chunk * cand_stride + path], cand_chunks[path]); the lane walks its candidates chunk by chunk in list
@@ -1405,16 +1403,15 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
     return bits;
 }
 
-// One block handles tiles of AGPT_BLOCK*SHADE_U queue entries.  Queue appends are aggregated per tile: ballots give
-// per-wave counts, one thread per queue scans them and reserves the tile's slots with ONE atomic, then every lane
-// writes its path id at its (order-preserving) offset -- 4 atomics per 1024 paths instead of 4 per wave: same-line
-// atomics serialise at ~11 ns each and were the kernel's bottleneck.
+// Every wave handles tiles of 64 * SHADE_U queue entries and aggregates its queue appends per tile: ballots give the per-queue
+// counts, ONE atomic per queue reserves the tile's slots, then every lane writes its path id at its (order-preserving) offset
+// -- same-line atomics serialise at ~11 ns each and were the kernel's bottleneck with one append per 64 paths.
 #ifndef SHADE_U
 #define SHADE_U 4
 #endif
 
-// 3 waves/SIMD: the register allocator is capped at 168 VGPRs (48 spilled to scratch); measured 127 ms per C3 step
-// against 140 ms at 2 waves (217 VGPRs, no spills) and 151 ms at 4 waves (96 spilled).
+// 3 waves/SIMD: the register allocator is capped at 168 VGPRs (21-27 of them spilled to scratch).  C3 step, non-trace time:
+// 2 waves (no spills) 94 ms, 3 waves 83 ms, 4 waves (128 VGPRs, ~90 spilled) 111 ms (re-measured in round 3).
 #ifndef AGPT_SHADE_WAVES
 #define AGPT_SHADE_WAVES 3
 #endif

@@ -140,6 +140,11 @@ AGPT_HD uint32_t wang_hash(uint32_t s) {
     s = s ^ (s >> 15);
     return s;
 }
+// One RandomFloat() stream per (pixel, sample): WangHash((pixel + W*H*sample + 1) * 17 + seed_base) (seeding convention of
+// cl/tools.cl:1-2).  The stream index is a 32-bit word like the hash's argument: it wraps once pixel + W*H*sample passes 2^32 --
+// at 3840x2160 from sample 518 on -- so a budget beyond that (BASELINE configs[4]: 1024 spp at 4K) re-uses streams of other
+// pixels' earlier samples.  The oracle indexes the same way (parity holds); hosts that need more than 2^32 distinct streams
+// split the budget over several seed_base values.
 AGPT_HD uint32_t sample_seed(uint32_t pixel, uint32_t wh, uint32_t sample, uint32_t seed_base) {
     uint32_t idx = pixel + wh * sample;
     uint32_t s = wang_hash((idx + 1u) * 17u + seed_base);

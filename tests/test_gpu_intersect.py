@@ -142,9 +142,10 @@ def test_plane_primitive():
     compare(d, 96, 96, 2)
 
 
-def test_deep_bvh_uses_the_64_entry_stack():
-    """A pathological mesh whose binned-SAH tree (depth 39) is deeper than the production kernel's 32-entry stack:
-    triangle sizes in geometric progression (x8) along one axis make every split peel off one triangle."""
+def test_deep_bvh_spills_the_traversal_stack():
+    """A pathological mesh whose binned-SAH tree (depth 39) is deeper than the 23 stack entries the production kernel keeps in LDS
+    (the rest live in its HBM spill column): triangle sizes in geometric progression (x8) along one axis make every split peel
+    off one triangle.  Closest-hit / any-hit records against the oracle, then a rendered image through the same spill path."""
     n = 40
     v, tris, scale = [], [], []
     x = 0.0
@@ -171,6 +172,12 @@ def test_deep_bvh_uses_the_64_entry_stack():
     rays["d"] = tgt - rays["o"]
     rays["tmax"] = 3.402823466e+38
     hit = check_closest(d, rays)
+    # the full path on the same mesh: camera in front of the largest triangles, sphere light + sky
+    from test_gpu_render import compare
+    d.add_area_light([float(x) * 0.5, float(scale[-1]), float(scale[-1]) * 2], float(scale[-1]) * 0.2, [30., 30., 30.])
+    d.add_uniform_infinite_light([.3, .3, .3])
+    d.set_camera([float(x) * 0.6, float(scale[-1]) * 0.3, float(scale[-1]) * 2.5], [float(x) * 0.6, float(scale[-1]) * 0.3, 0.0], [0, 1, 0], 1.0, 50.0, 0.0)
+    compare(d, 64, 64, 2)
 
 
 def test_degenerate_scenes_and_calls():
