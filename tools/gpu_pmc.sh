@@ -2,7 +2,7 @@
 # (copy the json and the *_kernel_stats.csv into profiles/).  One counter group per pass, --kernel-trace only.
 set -e
 cd $GRAFT_REPO_ROOT
-WL=${1:-c3}; TAG=${2:-r02_$WL}
+WL=${1:-c3}; TAG=${2:-r03_$WL}
 O=gpurun_out/pmc_$TAG
 mkdir -p $O
 export TMPDIR=/tmp
