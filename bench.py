@@ -289,20 +289,52 @@ def main():
     # The exchange at the end of a step.  Default: the product's own collective (agpt_gather_tiles) -- rank 0 creates the
     # ncclUniqueId through the C ABI, torch.distributed only carries its 128 bytes to the other ranks.  RCCL wants one GPU
     # per rank, so the several-ranks-on-one-GPU rehearsal (AGPT_BENCH_BACKEND=gloo) gathers through torch instead.
-    gather_mode = args.gather if (world > 1 and backend == "nccl") else ("torch" if world > 1 else "none")
+    gather_mode = args.gather if (world > 1 and (backend == "nccl" or os.environ.get("AGPT_BENCH_FORCE_AGPT_GATHER"))) else ("torch" if world > 1 else "none")
+    gather_note = None
+    xdev = dev if backend == "nccl" else torch.device("cpu")   # where the few control words of the set-up travel
     comm = None
     full_accum = None
     gather_bufs = None
-    if gather_mode == "agpt":
+
+    def all_ranks_ok(ok):
+        """True iff `ok` holds on every rank (the ranks must take the same branch afterwards)."""
         import torch.distributed as dist
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(ag.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0)
-        comm = ag.Comm(ctx, world, rank, unique_id=idt.cpu().numpy().tobytes())
-        if rank == 0:
-            full_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    elif gather_mode == "torch":
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    if gather_mode == "agpt":
+        # The product's collective has no other user in this process: set it up and run it once on an empty film before the
+        # timed region; if any rank reports an error (RCCL not loadable, communicator refused, ...) EVERY rank falls back to the
+        # torch.distributed gather and the bench line says so.
+        import torch.distributed as dist
+        err = None
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=xdev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(ag.comm_unique_id()), dtype=torch.uint8))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if all_ranks_ok(err is None):
+            dist.broadcast(idt, src=0)
+            try:
+                comm = ag.Comm(ctx, world, rank, unique_id=idt.cpu().numpy().tobytes())
+                if rank == 0:
+                    full_accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+                comm.gather_tiles(local.data_ptr(), W, H, tiles.BLOCK_ROWS, full_accum.data_ptr() if rank == 0 else 0)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err = e
+        if not all_ranks_ok(err is None):
+            gather_mode = "torch"
+            gather_note = "agpt_gather_tiles was requested and failed on a rank (%s): fell back to torch.distributed.gather" % (err,)
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                comm = None
+    if gather_mode == "torch":
         gather_bufs = tiles.alloc_gather_buffers(local, rank, world)   # receive buffers live outside the timed step
     # one agpt_render call per step and rank: the whole film at N = 1, this rank's interleaved 8-row blocks otherwise
     interleave = None if world == 1 else (tiles.BLOCK_ROWS, world, rank)
@@ -404,7 +436,7 @@ def main():
                 "triangles": desc.n_tris, "resolution": [W, H], "spp": spp,
                 "sharding": ("8-row blocks round-robin, one gather to rank 0 per step: %s"
                              % ("agpt_gather_tiles (C ABI: RCCL grouped send/recv over xGMI + k_deinterleave)" if gather_mode == "agpt"
-                                else "torch.distributed.gather (%s) + torch de-interleave" % backend)) if world > 1 else "single GPU",
+                                else "torch.distributed.gather (%s) + torch de-interleave%s" % (backend, "; " + gather_note if gather_note else ""))) if world > 1 else "single GPU",
                 # value counts the rays that entered a trace kernel (k_trace_fast launches: continuation / MIS query / shadow):
                 # value x ms_per_step = rays_traversed_per_step.  The reference algorithm's Scene::Intersect / IntersectP calls
                 # (equal to the CPU oracle's count) are reference_queries_per_step; the difference is settled exactly without a
