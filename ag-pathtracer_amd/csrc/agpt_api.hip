@@ -125,7 +125,8 @@ struct agpt_scene {
     bool committed = false;
     int max_depth = 0;
     DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade, d_prefilter;
-    DevBuf<uint32_t> d_toplevel, d_nodes4;
+    DevBuf<uint32_t> d_toplevel, d_nodes16;
+    DevBuf<float4> d_qscale;
     DevBuf<unsigned long long> d_chunk_mesh_masks;
     DevBuf<uint32_t> d_bigleaves;
     DevBuf<DevPrim> d_prims;
@@ -172,8 +173,8 @@ static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* q
     const dim3 block(AGPT_BLOCK), g(fast_grid(c));
     if (sc.n_prims <= 64) {
         if constexpr (!COUNT) {
-            if (c->fast_traversal) {   // tolerance mode: the 4-wide quantised trees (always with the HBM spill column)
-                hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, false, true, true>), g, block, 0, c->stream, sc, queue,
+            if (c->fast_traversal) {   // tolerance mode: quantised pair records
+                hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, false, SPILL, true>), g, block, 0, c->stream, sc, queue,
                                    count_ptr, count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0u, c->spill.p,
                                    (const unsigned long long*)nullptr, (const uint32_t*)nullptr);
                 return;
@@ -202,12 +203,10 @@ template <int MODE>
 static void launch_trace_fast_c(agpt_ctx* c, int count, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr,
                                 uint32_t count_imm, uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits,
                                 uint32_t* occ, int refill) {
-    // (tolerance mode: a 4-wide step pushes up to three entries, so the stack can reach 3 per level of the 4-wide tree)
-    const int stack_need = c->fast_traversal ? 3 * sc.max_depth4 + 4 : sc.max_depth;
-    const bool spill = stack_need > AGPT_FAST_STACK || c->fast_traversal;
+    const bool spill = sc.max_depth > AGPT_FAST_STACK;
     if (spill) {
-        // one column of (stack_need - AGPT_FAST_STACK) entries per thread of the grid
-        const size_t need = (size_t)std::max(1, stack_need - AGPT_FAST_STACK) * (size_t)fast_grid(c) * AGPT_BLOCK;
+        // one column of (max_depth - AGPT_FAST_STACK) entries per thread of the grid
+        const size_t need = (size_t)(sc.max_depth - AGPT_FAST_STACK) * (size_t)fast_grid(c) * AGPT_BLOCK;
         if (c->spill.ensure(need) != AGPT_OK) {
             c->note(hipErrorOutOfMemory);
             return;
@@ -354,7 +353,8 @@ void agpt_scene_destroy(agpt_scene* s) {
     s->d_tri_shade.release();
     s->d_prefilter.release();
     s->d_toplevel.release();
-    s->d_nodes4.release();
+    s->d_nodes16.release();
+    s->d_qscale.release();
     s->d_chunk_mesh_masks.release();
     s->d_prims.release();
     s->d_materials.release();
@@ -526,7 +526,8 @@ int agpt_scene_commit(agpt_scene* s) {
     if ((rc = upload(s->d_tri_shade, flat.tri_shade, st))) return rc;
     if ((rc = upload(s->d_prefilter, flat.prefilter, st))) return rc;
     if ((rc = upload(s->d_toplevel, flat.toplevel16, st))) return rc;
-    if ((rc = upload(s->d_nodes4, flat.nodes4, st))) return rc;
+    if ((rc = upload(s->d_nodes16, flat.nodes16, st))) return rc;
+    if ((rc = upload(s->d_qscale, flat.qscale, st))) return rc;
     {
         std::vector<unsigned long long> mm(flat.mesh_masks, flat.mesh_masks + AGPT_MAX_CHUNKS);
         if ((rc = upload(s->d_chunk_mesh_masks, mm, st))) return rc;
@@ -572,10 +573,8 @@ int agpt_scene_commit(agpt_scene* s) {
     for (int ch = 0; ch <= AGPT_MAX_CHUNKS; ch++) s->dev.pf_begin[ch] = flat.pf_begin[ch];
     s->dev.prefilter = s->d_prefilter.p;
     s->dev.toplevel = reinterpret_cast<const uint4*>(s->d_toplevel.p);
-    s->dev.nodes4 = reinterpret_cast<const uint4*>(s->d_nodes4.p);
-    s->dev.qorigin[0] = flat.qgrid[0].x; s->dev.qorigin[1] = flat.qgrid[0].y; s->dev.qorigin[2] = flat.qgrid[0].z;
-    s->dev.qstep[0] = flat.qgrid[1].x; s->dev.qstep[1] = flat.qgrid[1].y; s->dev.qstep[2] = flat.qgrid[1].z;
-    s->dev.max_depth4 = flat.max_depth4;
+    s->dev.nodes16 = reinterpret_cast<const uint4*>(s->d_nodes16.p);
+    s->dev.qscale = s->d_qscale.p;
     s->dev.n_toplevel = flat.n_toplevel;
     s->dev.chunk_mesh_masks = s->d_chunk_mesh_masks.p;
     s->dev.n_meshes = 0;

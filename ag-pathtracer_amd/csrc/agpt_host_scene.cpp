@@ -640,102 +640,51 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
         }
         out.prims.push_back(dp);
     }
-    // ---- tolerance mode: the trees collapsed to 4-wide nodes with quantised boxes --------------------------------------------
-    // One 64-byte record per 4-wide node: words [0..3] = x planes (lower | upper << 16) of children 0..3, [4..7] = y, [8..11] = z,
-    // [12..15] = the children's encodings (a leaf's as in the binary tree, an interior child's = the index of ITS 4-wide node,
-    // 0xFFFFFFFF = no child).  A 4-wide node is a binary node with its interior children replaced by their children.  All boxes
-    // sit on ONE 16-bit grid over the union of the mesh root boxes (origin = its lower corner, step = extent / 65535 rounded up),
-    // lower planes rounded down and upper planes up by one further cell: a quantised box CONTAINS the exact one.  The first
-    // prims.size() records are the root records: child 0 = the mesh's root box and root, nothing else.
-    {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        bool any = false;
-        for (const DevPrim& dp : out.prims) {
-            if (dp.type != AGPT_PRIM_MESH || dp.n_tris <= 0) continue;
-            any = true;
-            for (int a = 0; a < 3; a++) {
-                lo[a] = std::min(lo[a], (double)dp.root_bmin[a]);
-                hi[a] = std::max(hi[a], (double)dp.root_bmax[a]);
-            }
-        }
-        float origin[3] = {0, 0, 0}, step[3] = {0, 0, 0};
-        for (int a = 0; a < 3 && any; a++) {
-            origin[a] = (float)lo[a];
-            const double e = hi[a] - lo[a];
+    // ---- tolerance mode: quantised pair records ---------------------------------------------------------------------------
+    // Every box of a mesh on the 16-bit grid of the mesh's root box: origin = root bmin, step = extent / 65535 rounded up, lower
+    // planes rounded down and upper planes up by one further cell (the margin absorbs the rounding of the kernel's decode
+    // fma(q, step * R, (origin - O) * R)), so a quantised box CONTAINS the exact one and a ray that meets the exact box meets it.
+    out.nodes16.assign(8 * (node_base / 2 + 1), 0u);
+    out.qscale.assign(std::max<size_t>(prims.size(), 1), F4(0, 0, 0, 0));
+    for (size_t pi = 0; pi < prims.size(); pi++) {
+        const HostPrim& hp = prims[pi];
+        if (hp.type != AGPT_PRIM_MESH) continue;
+        const HostMesh& mesh = meshes[hp.index];
+        if (mesh.prim_index.empty()) continue;
+        const size_t nb = mesh_node_base[hp.index];
+        const agpt_bvh_node& root = mesh.nodes[0];
+        float step[3];
+        for (int a = 0; a < 3; a++) {
+            const double e = (double)root.bmax[a] - (double)root.bmin[a];
             float st = (float)(e / 65535.0 * (1.0 + 1e-6));
             while (e > 0 && (double)st * 65535.0 < e) st = std::nextafter(st, std::numeric_limits<float>::infinity());
             step[a] = e > 0 ? st : 0.f;
         }
-        out.qgrid[0] = F4(origin[0], origin[1], origin[2], 0.f);
-        out.qgrid[1] = F4(step[0], step[1], step[2], 0.f);
-        auto quantise = [&](const float bmin[3], const float bmax[3], uint32_t* rec, int slot) {
+        out.qscale[pi] = F4(step[0], step[1], step[2], 0.f);
+        for (size_t i = 0; i < mesh.nodes.size(); i++) {
+            if (i == 1) continue;  // unused slot
+            const agpt_bvh_node& n = mesh.nodes[i];
+            const size_t pair = (nb + i) >> 1, side = (nb + i) & 1;
+            uint32_t* rec = &out.nodes16[8 * pair + 4 * side];   // (x lo | hi << 16, y, z, encoding) of this side
             for (int a = 0; a < 3; a++) {
-                uint32_t ql = 0, qh = 0;
+                uint32_t lo = 0, hi = 0;
                 if (step[a] > 0) {
-                    const double l = std::floor(((double)bmin[a] - (double)origin[a]) / (double)step[a]) - 1.0;
-                    const double h = std::ceil(((double)bmax[a] - (double)origin[a]) / (double)step[a]) + 1.0;
-                    ql = (uint32_t)std::min(65535.0, std::max(0.0, l));
-                    qh = (uint32_t)std::min(65535.0, std::max(0.0, h));
+                    const double ql = std::floor(((double)n.bmin[a] - (double)root.bmin[a]) / (double)step[a]) - 1.0;
+                    const double qh = std::ceil(((double)n.bmax[a] - (double)root.bmin[a]) / (double)step[a]) + 1.0;
+                    lo = (uint32_t)std::min(65535.0, std::max(0.0, ql));
+                    hi = (uint32_t)std::min(65535.0, std::max(0.0, qh));
                 }
-                rec[4 * a + slot] = ql | (qh << 16);
+                rec[a] = lo | (hi << 16);
             }
-        };
-        std::vector<uint32_t>& n4 = out.nodes4;
-        n4.assign(16 * std::max<size_t>(prims.size(), 1), 0u);
-        for (size_t k = 0; k < n4.size() / 16; k++)
-            for (int j = 0; j < 4; j++) n4[16 * k + 12 + j] = 0xFFFFFFFFu;
-        out.max_depth4 = 0;
-        for (size_t pi = 0; pi < prims.size(); pi++) {
-            const HostPrim& hp = prims[pi];
-            if (hp.type != AGPT_PRIM_MESH) continue;
-            const HostMesh& mesh = meshes[hp.index];
-            if (mesh.prim_index.empty()) continue;
-            const size_t nb = mesh_node_base[hp.index];
-            // the binary node's traversal encoding (leaves) as flatten wrote it into the exact pair record
-            auto binary_enc = [&](size_t i) {
-                uint32_t z;
-                const float* ex = reinterpret_cast<const float*>(&out.nodes[4 * ((nb + i) >> 1)]);
-                std::memcpy(&z, &ex[12 + ((nb + i) & 1)], 4);
-                return z;
-            };
-            // iterative collapse (explicit work list: pathological trees are 60 levels deep)
-            struct Item { size_t node; size_t rec; int slot; int depth; };
-            std::vector<Item> work;
-            {
-                const agpt_bvh_node& r = mesh.nodes[0];
-                quantise(r.bmin, r.bmax, &n4[16 * pi], 0);
-                work.push_back({0, pi, 0, 1});
-            }
-            while (!work.empty()) {
-                const Item it = work.back();
-                work.pop_back();
-                const agpt_bvh_node& n = mesh.nodes[it.node];
-                if (n.count > 0) {   // leaf: its binary encoding
-                    n4[16 * it.rec + 12 + it.slot] = it.node == 0 ? out.prims[pi].root_enc : binary_enc(it.node);
-                    continue;
-                }
-                const size_t id = n4.size() / 16;
-                n4.resize(n4.size() + 16, 0u);
-                for (int j = 0; j < 4; j++) n4[16 * id + 12 + j] = 0xFFFFFFFFu;
-                n4[16 * it.rec + 12 + it.slot] = (uint32_t)id;
-                out.max_depth4 = std::max(out.max_depth4, it.depth);
-                size_t kids[4];
-                int nk = 0;
-                for (int c = 0; c < 2; c++) {
-                    const size_t ch = (size_t)n.first + c;
-                    const agpt_bvh_node& cn = mesh.nodes[ch];
-                    if (cn.count > 0) {
-                        kids[nk++] = ch;
-                    } else {
-                        kids[nk++] = (size_t)cn.first;
-                        kids[nk++] = (size_t)cn.first + 1;
-                    }
-                }
-                for (int j = 0; j < nk; j++) {
-                    quantise(mesh.nodes[kids[j]].bmin, mesh.nodes[kids[j]].bmax, &n4[16 * id], j);
-                    work.push_back({kids[j], id, j, it.depth + 1});
-                }
-            }
+            // the same traversal encoding as the exact record's (its .z word)
+            const float* exact = reinterpret_cast<const float*>(&out.nodes[4 * pair]);
+            std::memcpy(&rec[3], &exact[12 + side], 4);
+        }
+        // a pair whose other half does not exist (the root's slot 1): an empty box there
+        if ((nb & 1) == 0) {
+            uint32_t* rec = &out.nodes16[8 * (nb >> 1) + 4];
+            rec[0] = rec[1] = rec[2] = 0x0000FFFFu;   // lo = 65535 > hi = 0 on every axis
+            rec[3] = 0;
         }
     }
 

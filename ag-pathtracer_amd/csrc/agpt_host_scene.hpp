@@ -77,11 +77,10 @@ struct FlatScene {
     std::vector<float4> toplevel;       // builder output (fp32 boxes)
     std::vector<uint32_t> toplevel16;   // the same tree as the device reads it: 4 words per node, boxes rounded outward to fp16
     int32_t n_toplevel = 0;
-    // opt-in tolerance mode (agpt_render_params::fast_traversal; agpt_scene.h): the trees collapsed to 4-wide nodes of 16 words
-    // with boxes on one 16-bit grid (qgrid[0] = origin.xyz, qgrid[1] = step.xyz); the first prims.size() records are root records
-    std::vector<uint32_t> nodes4;
-    float4 qgrid[2] = {};
-    int max_depth4 = 0;   // deepest 4-wide tree (levels of 4-wide nodes)
+    // opt-in tolerance mode (agpt_render_params::fast_traversal; agpt_scene.h): 32-byte pair records with the boxes on a 16-bit
+    // grid of their mesh's root box, rounded outward -- 8 words per pair -- and the grid step per primitive (xyz; 0 for non-meshes)
+    std::vector<uint32_t> nodes16;
+    std::vector<float4> qscale;
 };
 // 16-byte nodes from build_skip_tree's output: (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, skip | leaf << 16),
 // box coordinates as IEEE half rounded outward (lo down, hi up), skip / leaf as 16-bit indices (leaf 0xFFFF = interior)

@@ -242,13 +242,13 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 #ifndef AGPT_TRACE_WAVES
 #define AGPT_TRACE_WAVES 1   // minimum waves per SIMD the register allocation of k_trace_fast is held to
 #endif
-// FAST (agpt_render_params::fast_traversal, opt-in tolerance mode; short lists, no counters, always with the HBM spill column):
-// the traversal walks the 4-WIDE collapse of the trees (DevScene::nodes4): an interior step reads one 64-byte record with the
-// outward-rounded 16-bit boxes of up to four children, tests them with one fma per plane (t = fma(q, step * R, (origin - O) * R)
-// with per-axis error bounds folded into the constants), goes to the nearest child hit and pushes the others farthest first.
-// Half the interior steps of the binary walk.  The leaves visited are a superset of the exact traversal's and run the same exact
-// triangle test: the hit returned is the nearest accepted one over that superset -- it differs from the reference's only where
-// the reference's own rounded box test prunes a triangle the ray grazes, or in the order of two hits at equal distance.
+// FAST (agpt_render_params::fast_traversal, opt-in tolerance mode; short lists, no counters): interior steps read the 32-byte
+// quantised pair records (DevScene::nodes16) -- two 16-byte loads instead of four -- and test the outward-rounded boxes with one
+// fma per plane (t = fma(q, step * R, (origin - O) * R), the prefilter's conservative form and slack) instead of the reference's
+// exact quotients; a mesh is entered at its root's children (the prefilter has already met the root box).  The nodes visited are
+// a superset of the exact traversal's, leaves run the same exact triangle test: the hit returned is the nearest accepted one
+// over that superset.  It differs from the reference's only where the reference's own rounded box test prunes a triangle the
+// ray grazes, or in the order of two hits at equal distance.
 template <int MODE, int DEPTH, bool LIST, bool COUNT, bool SPILL, bool FAST = false>
 __global__ void __launch_bounds__(AGPT_BLOCK, AGPT_TRACE_WAVES)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
@@ -292,7 +292,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         } else {
             a.x = P.root_bmin[0]; a.y = P.root_bmin[1]; a.z = P.root_bmin[2]; a.w = P.n_tris > 0 ? 0.f : 2.f;
             b.x = P.root_bmax[0]; b.y = P.root_bmax[1]; b.z = P.root_bmax[2]; b.w = __uint_as_float(P.root_enc);
-
+            if (FAST) {   // the grid of the mesh's quantised boxes: origin = root bmin, step
+                const float4 qs = sc.qscale[threadIdx.x];
+                b.x = qs.x; b.y = qs.y; b.z = qs.z;
+            }
         }
         s_prim[2 * threadIdx.x] = a;
         s_prim[2 * threadIdx.x + 1] = b;
@@ -354,7 +357,23 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         if (low & mesh_mask0) {
             m ^= low;
             const uint32_t k = (uint32_t)(__ffsll((long long)low) - 1);
-            if (FAST) return k;   // the mesh's root record of the 4-wide tree (records 0 .. n_prims-1)
+            if (FAST) {   // straight to the root node (the prefilter has met the root box), on this mesh's grid
+                const float4 ga = s_prim[2 * k], gb = s_prim[2 * k + 1];
+                // t(q) = fma(q, A, B) with A = step * R, B = (origin - O) * R differs from the real ((origin + q * step) - O) / D
+                // by at most ~2^-23 (|B| + 65535 |A|): each axis' bound is folded into its own constants, so that a nearly
+                // axis-parallel ray (huge R on one axis) loosens that axis only
+                auto axis = [](float step, float origin, float o, float rcp, float& a, float& b0, float& b1) {
+                    a = step * rcp;
+                    const float b = (origin - o) * rcp;
+                    const float e = 0x1p-21f * (fabsf(b) + 65535.f * fabsf(a));
+                    b0 = a < 0.f ? b + e : b - e;   // the lower plane is the entry plane for a > 0, the exit plane otherwise
+                    b1 = a < 0.f ? b - e : b + e;
+                };
+                axis(gb.x, ga.x, r.O.x, r.R.x, qA.x, qB0.x, qB1.x);
+                axis(gb.y, ga.y, r.O.y, r.R.y, qA.y, qB0.y, qB1.y);
+                axis(gb.z, ga.z, r.O.z, r.R.z, qA.z, qB0.z, qB1.z);
+                return __float_as_uint(gb.w);
+            }
             return rootpair_base + 2u * k;
         }
         return CUR_PICK;
@@ -587,19 +606,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                         r.R = V3(1.0f / copysignf(fmaxf(fabsf(d.x), lim), d.x), 1.0f / copysignf(fmaxf(fabsf(d.y), lim), d.y),
                                  1.0f / copysignf(fmaxf(fabsf(d.z), lim), d.z));
                         r.fast = true;
-                        // t(q) = fma(q, A, B) with A = step * R, B = (origin - O) * R differs from the real ((origin + q * step) - O) / D
-                        // by at most ~2^-23 (|B| + 65535 |A|): each axis' bound is folded into its own constants, so that a nearly
-                        // axis-parallel ray (huge R on one axis) loosens that axis only
-                        auto axis = [](float step, float origin, float ro, float rcp, float& a, float& b0, float& b1) {
-                            a = step * rcp;
-                            const float b = (origin - ro) * rcp;
-                            const float e = 0x1p-21f * (fabsf(b) + 65535.f * fabsf(a));
-                            b0 = a < 0.f ? b + e : b - e;   // the lower plane is the entry plane for a > 0, the exit plane otherwise
-                            b1 = a < 0.f ? b - e : b + e;
-                        };
-                        axis(sc.qstep[0], sc.qorigin[0], o.x, r.R.x, qA.x, qB0.x, qB1.x);
-                        axis(sc.qstep[1], sc.qorigin[1], o.y, r.R.y, qA.y, qB0.y, qB1.y);
-                        axis(sc.qstep[2], sc.qorigin[2], o.z, r.R.z, qA.z, qB0.z, qB1.z);
                     }
                     rayt = o.w;
                     if (MIS) {
@@ -654,53 +660,15 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     // waves in the middle of their arithmetic (-1.5 ms per C3 step on the closest-hit and MIS launches; the
                     // short any-hit steps lose 0.3 ms with it)
                     if (MODE != 1) __builtin_amdgcn_s_setprio(1);
-                    if constexpr (FAST) {
-                        // ---- 4-wide step on quantised boxes (tolerance mode) ----
-                        const uint4* rec = sc.nodes4 + 4 * (size_t)cur;
-                        const uint4 qx = rec[0], qy = rec[1], qz = rec[2], qe = rec[3];
-                        if (MODE != 1) {
-                            asm volatile("" ::: "memory");
-                            __builtin_amdgcn_s_setprio(0);
-                        }
-                        // entry distance of a child's box, +inf when the ray misses it (or the slot is empty)
-                        auto child = [&](uint32_t wx, uint32_t wy, uint32_t wz, uint32_t enc) -> float {
-                            const float x0 = __builtin_fmaf((float)(wx & 0xFFFFu), qA.x, qB0.x), x1 = __builtin_fmaf((float)(wx >> 16), qA.x, qB1.x);
-                            const float y0 = __builtin_fmaf((float)(wy & 0xFFFFu), qA.y, qB0.y), y1 = __builtin_fmaf((float)(wy >> 16), qA.y, qB1.y);
-                            const float z0 = __builtin_fmaf((float)(wz & 0xFFFFu), qA.z, qB0.z), z1 = __builtin_fmaf((float)(wz >> 16), qA.z, qB1.z);
-                            const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.f));
-                            const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), rayt));
-                            const bool hit = !(tmax * 1.000002f < tmin) && enc != 0xFFFFFFFFu;
-                            return hit ? tmin : __builtin_inff();
-                        };
-                        float d0 = child(qx.x, qy.x, qz.x, qe.x), d1 = child(qx.y, qy.y, qz.y, qe.y);
-                        float d2 = child(qx.z, qy.z, qz.z, qe.z), d3 = child(qx.w, qy.w, qz.w, qe.w);
-                        uint32_t e0 = qe.x, e1 = qe.y, e2 = qe.z, e3 = qe.w;
-                        // sort the four (distance, child) pairs by distance: the children hit come first, nearest first
-                        auto cswap = [](float& da, uint32_t& ea, float& db, uint32_t& eb) {
-                            const bool sw = db < da;
-                            const float dn = sw ? db : da, df = sw ? da : db;
-                            const uint32_t en = sw ? eb : ea, ef = sw ? ea : eb;
-                            da = dn; db = df; ea = en; eb = ef;
-                        };
-                        cswap(d0, e0, d1, e1);
-                        cswap(d2, e2, d3, e3);
-                        cswap(d0, e0, d2, e2);
-                        cswap(d1, e1, d3, e3);
-                        cswap(d1, e1, d2, e2);
-                        const float inf = __builtin_inff();
-                        if (d0 < inf) {   // at least one child: go to the nearest, push the rest farthest first
-                            if (d3 < inf) { stack_push(sp, e3); sp++; }
-                            if (d2 < inf) { stack_push(sp, e2); sp++; }
-                            if (d1 < inf) { stack_push(sp, e1); sp++; }
-                            cur = e0;
-                        } else if (sp == 0) {
-                            cur = pick_next(mask);
-                        } else {
-                            sp--;
-                            cur = stack_at(sp);
-                        }
+                    NodePair np;
+                    uint4 ql, qr;
+                    if (FAST) {
+                        const uint4* rec = sc.nodes16 + cur;   // two uint4 per pair, cur = index of the pair's left node
+                        ql = rec[0];
+                        qr = rec[1];
                     } else {
-                    const NodePair np = load_pair(sc, cur);
+                        np = load_pair(sc, cur);
+                    }
                     if (MODE != 1) {
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_s_setprio(0);
@@ -708,10 +676,33 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     TCK(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk_bmem += TCK_NOW() - tk_v1;)
                     float dl, dr;
                     bool hl, hr;
-                    const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
-                    pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
-                    if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
-                        if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
+                    uint32_t encl, encr;
+                    if (FAST) {
+                        auto qbox = [&](const uint4 q, float& dist) -> bool {
+#ifdef AGPT_X_NOSDWA
+                            auto cv = [](uint32_t v) { asm volatile("" : "+v"(v)); return (float)v; };
+#else
+                            auto cv = [](uint32_t v) { return (float)v; };
+#endif
+                            const float x0 = __builtin_fmaf(cv(q.x & 0xFFFFu), qA.x, qB0.x), x1 = __builtin_fmaf(cv(q.x >> 16), qA.x, qB1.x);
+                            const float y0 = __builtin_fmaf(cv(q.y & 0xFFFFu), qA.y, qB0.y), y1 = __builtin_fmaf(cv(q.y >> 16), qA.y, qB1.y);
+                            const float z0 = __builtin_fmaf(cv(q.z & 0xFFFFu), qA.z, qB0.z), z1 = __builtin_fmaf(cv(q.z >> 16), qA.z, qB1.z);
+                            const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.f));
+                            const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), rayt));
+                            dist = tmin;
+                            return !(tmax * 1.000002f < tmin);
+                        };
+                        hl = qbox(ql, dl);
+                        hr = qbox(qr, dr);
+                        encl = ql.w;
+                        encr = qr.w;
+                    } else {
+                        encl = __float_as_uint(np.n3.x);
+                        encr = __float_as_uint(np.n3.y);
+                        pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
+                        if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
+                            if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
+                        }
                     }
                     if (COUNT) {
                         if (cur < rootpair_base) c_int++; else c_root++;
@@ -732,7 +723,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     } else {
                         sp--;
                         cur = stack_at(sp);
-                    }
                     }
                 }
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_balu += TCK_NOW() - tk_v1;)

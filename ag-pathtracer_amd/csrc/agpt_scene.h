@@ -127,16 +127,13 @@ struct DevScene {
     const uint4* toplevel;   // 16-byte nodes, see below
     int32_t n_toplevel;
     const unsigned long long* chunk_mesh_masks;   // mesh_masks[] again, in global memory (per-lane chunk index)
-    // Tolerance mode (agpt_render_params::fast_traversal, off by default): the same trees collapsed to 4-WIDE nodes with
-    // quantised boxes.  nodes4[4 * k .. 4 * k + 3] = node k: (x planes of children 0..3), (y planes), (z planes), (encodings), a
-    // plane word = lower | upper << 16 on ONE 16-bit grid over all meshes (origin qorigin, step qstep), rounded outward: the
-    // quantised box contains the exact one.  Encodings: a leaf's as in the binary tree, an interior child's = its 4-wide node's
-    // index, 0xFFFFFFFF = no child.  Records 0 .. n_prims-1 are root records (child 0 = the mesh's root box and root).  Half the
-    // interior steps of the binary traversal at the same 64 bytes per step; the traversal visits a superset of the exact
-    // traversal's leaves and tests their triangles exactly.
-    const uint4* nodes4;
-    float qorigin[3], qstep[3];
-    int32_t max_depth4;
+    // Tolerance mode (agpt_render_params::fast_traversal, off by default): the same trees with 32-byte pair records --
+    // nodes16[2 * pair] = (x, y, z, encoding) of the left node, [2 * pair + 1] of the right one, each coordinate word holding the
+    // box's lower | upper << 16 plane on the 16-bit grid of the mesh's root box (origin = root bmin, step = qscale[prim].xyz),
+    // rounded outward: the quantised box contains the exact one.  Half the bytes and half the vector-memory accesses of an
+    // interior step; the traversal visits a superset of the exact traversal's nodes and tests the same triangles exactly.
+    const uint4* nodes16;
+    const float4* qscale;
     DevCamera cam;
 };
 

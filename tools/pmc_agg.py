@@ -10,14 +10,14 @@ for f in sys.argv[1:]:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:64]
+        k = r["Kernel_Name"].split("(")[0][:48]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k].add(r["Dispatch_Id"])
     dur = collections.defaultdict(float)
     kt = f.replace("_counter_collection.csv", "_kernel_trace.csv")
     if os.path.exists(kt):
         for r in csv.DictReader(open(kt)):
-            dur[r["Kernel_Name"].split("(")[0][:64]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            dur[r["Kernel_Name"].split("(")[0][:48]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     print("== %s" % f)
     for k, d in sorted(agg.items()):
         if not any(s in k for s in ("k_trace", "k_shade", "k_generate", "k_accumulate")):
