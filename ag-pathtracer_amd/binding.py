@@ -66,7 +66,7 @@ class RenderParams(C.Structure):
                 ("seed_base", C.c_uint32), ("max_depth", C.c_int32), ("accum_pitch", C.c_int32),
                 ("accum_row0", C.c_int32), ("samples_per_batch", C.c_int32), ("enable_counters", C.c_int32),
                 ("enable_timing", C.c_int32), ("interleave_block", C.c_int32), ("interleave_world", C.c_int32),
-                ("interleave_rank", C.c_int32), ("trace_all_rays", C.c_int32), ("fast_traversal", C.c_int32)]
+                ("interleave_rank", C.c_int32), ("trace_all_rays", C.c_int32)]
 
 
 def library_path():
@@ -501,8 +501,7 @@ class PathTracer:
         self.MaxDepth = int(maxDepth)
 
     def render(self, scene, W, H, spp, accum_ptr, tile=None, spp_begin=0, seed_base=0, accum_pitch=None, accum_row0=0,
-               samples_per_batch=0, counters=False, timing=False, want_stats=True, interleave=None, trace_all_rays=False,
-               fast_traversal=False):
+               samples_per_batch=0, counters=False, timing=False, want_stats=True, interleave=None, trace_all_rays=False):
         """Adds `spp` samples per pixel of `tile` (x0, y0, w, h) into the DEVICE float4 buffer at accum_ptr.
         interleave=(block_rows, world, rank) renders this rank's row blocks of the whole film into its compact buffer
         (see tiles.py) in one call.  counters: False/0 = off, True/1 = the reference-order instrumented kernel (the
@@ -511,8 +510,7 @@ class PathTracer:
         il = interleave if interleave is not None else (0, 0, 0)
         rp = RenderParams(W, H, x0, y0, w, h, spp_begin, spp, seed_base & 0xFFFFFFFF, self.MaxDepth,
                           accum_pitch if accum_pitch is not None else W, accum_row0, samples_per_batch,
-                          int(counters), 1 if timing else 0, il[0], il[1], il[2], 1 if trace_all_rays else 0,
-                          1 if fast_traversal else 0)
+                          int(counters), 1 if timing else 0, il[0], il[1], il[2], 1 if trace_all_rays else 0)
         st = Stats()
         _check(scene.L.agpt_render(scene.h, C.byref(rp), C.c_void_p(int(accum_ptr)), C.byref(st) if want_stats else None),
                "agpt_render")

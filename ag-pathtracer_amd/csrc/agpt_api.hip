@@ -94,7 +94,6 @@ struct agpt_ctx {
     int refill_any = AGPT_REFILL_ANY;  // AGPT_REFILL_ANY: same for the any-hit / MIS-query launches
     bool mis_closest = false;    // AGPT_MIS_CLOSEST=1: trace MIS rays as full closest-hit queries (A/B, tests)
     bool force_generic = false;  // AGPT_FORCE_GENERIC=1: always use the generic k_trace (tests)
-    bool fast_traversal = false; // set per agpt_render call from agpt_render_params::fast_traversal (tolerance mode)
     // per-launch HIP-event timing of the trace kernels (agpt_render_params::enable_timing)
     std::vector<hipEvent_t> tev;
     size_t tev_used = 0;
@@ -125,8 +124,7 @@ struct agpt_scene {
     bool committed = false;
     int max_depth = 0;
     DevBuf<float4> d_nodes, d_tri_verts, d_tri_shade, d_prefilter;
-    DevBuf<uint32_t> d_toplevel, d_nodes16;
-    DevBuf<float4> d_qscale;
+    DevBuf<uint32_t> d_toplevel;
     DevBuf<unsigned long long> d_chunk_mesh_masks;
     DevBuf<uint32_t> d_bigleaves;
     DevBuf<DevPrim> d_prims;
@@ -172,14 +170,6 @@ static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* q
                               uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, int refill) {
     const dim3 block(AGPT_BLOCK), g(fast_grid(c));
     if (sc.n_prims <= 64) {
-        if constexpr (!COUNT) {
-            if (c->fast_traversal) {   // tolerance mode: quantised pair records
-                hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, false, SPILL, true>), g, block, 0, c->stream, sc, queue,
-                                   count_ptr, count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0u, c->spill.p,
-                                   (const unsigned long long*)nullptr, (const uint32_t*)nullptr);
-                return;
-            }
-        }
         hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, COUNT, SPILL>), g, block, 0, c->stream, sc, queue, count_ptr,
                            count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0u, c->spill.p,
                            (const unsigned long long*)nullptr, (const uint32_t*)nullptr);
@@ -353,8 +343,6 @@ void agpt_scene_destroy(agpt_scene* s) {
     s->d_tri_shade.release();
     s->d_prefilter.release();
     s->d_toplevel.release();
-    s->d_nodes16.release();
-    s->d_qscale.release();
     s->d_chunk_mesh_masks.release();
     s->d_prims.release();
     s->d_materials.release();
@@ -526,8 +514,6 @@ int agpt_scene_commit(agpt_scene* s) {
     if ((rc = upload(s->d_tri_shade, flat.tri_shade, st))) return rc;
     if ((rc = upload(s->d_prefilter, flat.prefilter, st))) return rc;
     if ((rc = upload(s->d_toplevel, flat.toplevel16, st))) return rc;
-    if ((rc = upload(s->d_nodes16, flat.nodes16, st))) return rc;
-    if ((rc = upload(s->d_qscale, flat.qscale, st))) return rc;
     {
         std::vector<unsigned long long> mm(flat.mesh_masks, flat.mesh_masks + AGPT_MAX_CHUNKS);
         if ((rc = upload(s->d_chunk_mesh_masks, mm, st))) return rc;
@@ -573,8 +559,6 @@ int agpt_scene_commit(agpt_scene* s) {
     for (int ch = 0; ch <= AGPT_MAX_CHUNKS; ch++) s->dev.pf_begin[ch] = flat.pf_begin[ch];
     s->dev.prefilter = s->d_prefilter.p;
     s->dev.toplevel = reinterpret_cast<const uint4*>(s->d_toplevel.p);
-    s->dev.nodes16 = reinterpret_cast<const uint4*>(s->d_nodes16.p);
-    s->dev.qscale = s->d_qscale.p;
     s->dev.n_toplevel = flat.n_toplevel;
     s->dev.chunk_mesh_masks = s->d_chunk_mesh_masks.p;
     s->dev.n_meshes = 0;
@@ -911,13 +895,6 @@ int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, a
     bind_pool(c, pb, q);
     WavefrontRun run;
     run.count = rp->enable_counters == 2 ? 2 : (rp->enable_counters != 0 ? 1 : 0);
-    // tolerance mode: the production kernel for short lists without counters has the quantised-box instantiation; every other
-    // combination renders exactly (the flag is a permission, not a request that can fail)
-    struct FastScope {
-        agpt_ctx* c;
-        ~FastScope() { c->fast_traversal = false; }
-    } fast_scope{c};
-    c->fast_traversal = rp->fast_traversal != 0 && run.count == 0;
     run.mis_mode = use_fast_trace(c, s->dev, run.count) && !c->mis_closest;
     run.timing = rp->enable_timing != 0 && stats != nullptr;
     run.shade_lds_tables = shade_tables_fit_lds(s->dev);

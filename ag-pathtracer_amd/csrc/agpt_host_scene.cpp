@@ -5,7 +5,6 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
-#include <limits>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -640,54 +639,6 @@ void flatten_scene(const std::vector<HostMesh>& meshes, const std::vector<HostSp
         }
         out.prims.push_back(dp);
     }
-    // ---- tolerance mode: quantised pair records ---------------------------------------------------------------------------
-    // Every box of a mesh on the 16-bit grid of the mesh's root box: origin = root bmin, step = extent / 65535 rounded up, lower
-    // planes rounded down and upper planes up by one further cell (the margin absorbs the rounding of the kernel's decode
-    // fma(q, step * R, (origin - O) * R)), so a quantised box CONTAINS the exact one and a ray that meets the exact box meets it.
-    out.nodes16.assign(8 * (node_base / 2 + 1), 0u);
-    out.qscale.assign(std::max<size_t>(prims.size(), 1), F4(0, 0, 0, 0));
-    for (size_t pi = 0; pi < prims.size(); pi++) {
-        const HostPrim& hp = prims[pi];
-        if (hp.type != AGPT_PRIM_MESH) continue;
-        const HostMesh& mesh = meshes[hp.index];
-        if (mesh.prim_index.empty()) continue;
-        const size_t nb = mesh_node_base[hp.index];
-        const agpt_bvh_node& root = mesh.nodes[0];
-        float step[3];
-        for (int a = 0; a < 3; a++) {
-            const double e = (double)root.bmax[a] - (double)root.bmin[a];
-            float st = (float)(e / 65535.0 * (1.0 + 1e-6));
-            while (e > 0 && (double)st * 65535.0 < e) st = std::nextafter(st, std::numeric_limits<float>::infinity());
-            step[a] = e > 0 ? st : 0.f;
-        }
-        out.qscale[pi] = F4(step[0], step[1], step[2], 0.f);
-        for (size_t i = 0; i < mesh.nodes.size(); i++) {
-            if (i == 1) continue;  // unused slot
-            const agpt_bvh_node& n = mesh.nodes[i];
-            const size_t pair = (nb + i) >> 1, side = (nb + i) & 1;
-            uint32_t* rec = &out.nodes16[8 * pair + 4 * side];   // (x lo | hi << 16, y, z, encoding) of this side
-            for (int a = 0; a < 3; a++) {
-                uint32_t lo = 0, hi = 0;
-                if (step[a] > 0) {
-                    const double ql = std::floor(((double)n.bmin[a] - (double)root.bmin[a]) / (double)step[a]) - 1.0;
-                    const double qh = std::ceil(((double)n.bmax[a] - (double)root.bmin[a]) / (double)step[a]) + 1.0;
-                    lo = (uint32_t)std::min(65535.0, std::max(0.0, ql));
-                    hi = (uint32_t)std::min(65535.0, std::max(0.0, qh));
-                }
-                rec[a] = lo | (hi << 16);
-            }
-            // the same traversal encoding as the exact record's (its .z word)
-            const float* exact = reinterpret_cast<const float*>(&out.nodes[4 * pair]);
-            std::memcpy(&rec[3], &exact[12 + side], 4);
-        }
-        // a pair whose other half does not exist (the root's slot 1): an empty box there
-        if ((nb & 1) == 0) {
-            uint32_t* rec = &out.nodes16[8 * (nb >> 1) + 4];
-            rec[0] = rec[1] = rec[2] = 0x0000FFFFu;   // lo = 65535 > hi = 0 on every axis
-            rec[3] = 0;
-        }
-    }
-
     // prefilter table + analytic-primitive masks of the production trace kernel (agpt_scene.h)
     out.prefilter.clear();
     for (int c = 0; c <= AGPT_MAX_CHUNKS; c++) out.pf_begin[c] = 0;

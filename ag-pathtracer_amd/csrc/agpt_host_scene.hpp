@@ -77,10 +77,6 @@ struct FlatScene {
     std::vector<float4> toplevel;       // builder output (fp32 boxes)
     std::vector<uint32_t> toplevel16;   // the same tree as the device reads it: 4 words per node, boxes rounded outward to fp16
     int32_t n_toplevel = 0;
-    // opt-in tolerance mode (agpt_render_params::fast_traversal; agpt_scene.h): 32-byte pair records with the boxes on a 16-bit
-    // grid of their mesh's root box, rounded outward -- 8 words per pair -- and the grid step per primitive (xyz; 0 for non-meshes)
-    std::vector<uint32_t> nodes16;
-    std::vector<float4> qscale;
 };
 // 16-byte nodes from build_skip_tree's output: (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, skip | leaf << 16),
 // box coordinates as IEEE half rounded outward (lo down, hi up), skip / leaf as 16-bit indices (leaf 0xFFFF = interior)

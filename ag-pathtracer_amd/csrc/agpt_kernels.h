@@ -242,14 +242,7 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 #ifndef AGPT_TRACE_WAVES
 #define AGPT_TRACE_WAVES 1   // minimum waves per SIMD the register allocation of k_trace_fast is held to
 #endif
-// FAST (agpt_render_params::fast_traversal, opt-in tolerance mode; short lists, no counters): interior steps read the 32-byte
-// quantised pair records (DevScene::nodes16) -- two 16-byte loads instead of four -- and test the outward-rounded boxes with one
-// fma per plane (t = fma(q, step * R, (origin - O) * R), the prefilter's conservative form and slack) instead of the reference's
-// exact quotients; a mesh is entered at its root's children (the prefilter has already met the root box).  The nodes visited are
-// a superset of the exact traversal's, leaves run the same exact triangle test: the hit returned is the nearest accepted one
-// over that superset.  It differs from the reference's only where the reference's own rounded box test prunes a triangle the
-// ray grazes, or in the order of two hits at equal distance.
-template <int MODE, int DEPTH, bool LIST, bool COUNT, bool SPILL, bool FAST = false>
+template <int MODE, int DEPTH, bool LIST, bool COUNT, bool SPILL>
 __global__ void __launch_bounds__(AGPT_BLOCK, AGPT_TRACE_WAVES)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
@@ -292,10 +285,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         } else {
             a.x = P.root_bmin[0]; a.y = P.root_bmin[1]; a.z = P.root_bmin[2]; a.w = P.n_tris > 0 ? 0.f : 2.f;
             b.x = P.root_bmax[0]; b.y = P.root_bmax[1]; b.z = P.root_bmax[2]; b.w = __uint_as_float(P.root_enc);
-            if (FAST) {   // the grid of the mesh's quantised boxes: origin = root bmin, step
-                const float4 qs = sc.qscale[threadIdx.x];
-                b.x = qs.x; b.y = qs.y; b.z = qs.z;
-            }
         }
         s_prim[2 * threadIdx.x] = a;
         s_prim[2 * threadIdx.x + 1] = b;
@@ -335,15 +324,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     // Scene::Intersect's walk to the next primitive of the list (scene.h:8-17).  A mesh is entered through its root
     // pair -- the root-box test becomes the lane's next interior step (state B); spheres, planes and the end of the
     // list go through state A.
-    TraceRay r;
-    r.O = V3s(0.f);
-    r.D = V3(0.f, 0.f, 1.f);
-    r.R = V3s(1.f);
-    r.fast = true;
-    static_assert(!FAST || (!LIST && !COUNT), "the tolerance-mode kernel exists for short lists without counters");
-    // FAST lane state: the current mesh's grid in ray space -- t = fma(q, qA, qB) per axis -- and the slack of that form
-    // (qB0 goes with a box's lower plane, qB1 with its upper one: each carries the form's error bound of ITS axis, pushed outward)
-    v3 qA = V3s(0.f), qB0 = V3s(0.f), qB1 = V3s(0.f);
     auto pick_next = [&](unsigned long long& m) -> uint32_t {
         const unsigned long long low = m & (0ull - m);
         if (LIST) {
@@ -356,25 +336,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         }
         if (low & mesh_mask0) {
             m ^= low;
-            const uint32_t k = (uint32_t)(__ffsll((long long)low) - 1);
-            if (FAST) {   // straight to the root node (the prefilter has met the root box), on this mesh's grid
-                const float4 ga = s_prim[2 * k], gb = s_prim[2 * k + 1];
-                // t(q) = fma(q, A, B) with A = step * R, B = (origin - O) * R differs from the real ((origin + q * step) - O) / D
-                // by at most ~2^-23 (|B| + 65535 |A|): each axis' bound is folded into its own constants, so that a nearly
-                // axis-parallel ray (huge R on one axis) loosens that axis only
-                auto axis = [](float step, float origin, float o, float rcp, float& a, float& b0, float& b1) {
-                    a = step * rcp;
-                    const float b = (origin - o) * rcp;
-                    const float e = 0x1p-21f * (fabsf(b) + 65535.f * fabsf(a));
-                    b0 = a < 0.f ? b + e : b - e;   // the lower plane is the entry plane for a > 0, the exit plane otherwise
-                    b1 = a < 0.f ? b - e : b + e;
-                };
-                axis(gb.x, ga.x, r.O.x, r.R.x, qA.x, qB0.x, qB1.x);
-                axis(gb.y, ga.y, r.O.y, r.R.y, qA.y, qB0.y, qB1.y);
-                axis(gb.z, ga.z, r.O.z, r.R.z, qA.z, qB0.z, qB1.z);
-                return __float_as_uint(gb.w);
-            }
-            return rootpair_base + 2u * k;
+            return rootpair_base + 2u * (uint32_t)(__ffsll((long long)low) - 1);
         }
         return CUR_PICK;
     };
@@ -401,6 +363,11 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     uint32_t cur = CUR_IDLE, hid = AGPT_HIT_MISS;
     int sp = 0;
     float rayt = 0.f, hb1 = 0.f, hb2 = 0.f;
+    TraceRay r;
+    r.O = V3s(0.f);
+    r.D = V3(0.f, 0.f, 1.f);
+    r.R = V3s(1.f);
+    r.fast = true;
 
     // wave-private ring of pre-filtered rays (path id + primitive mask), filled 64 rays at a time
     __shared__ uint32_t s_ring_pid[BLOCK / 64][AGPT_RING];
@@ -601,12 +568,6 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                     float4 o = ray_o[pid], d = ray_d[pid];
                     r = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
-                    if (FAST) {   // (a direction component below 2^-40 is tested as +-2^-40: finite reciprocals)
-                        const float lim = 0x1p-40f;
-                        r.R = V3(1.0f / copysignf(fmaxf(fabsf(d.x), lim), d.x), 1.0f / copysignf(fmaxf(fabsf(d.y), lim), d.y),
-                                 1.0f / copysignf(fmaxf(fabsf(d.z), lim), d.z));
-                        r.fast = true;
-                    }
                     rayt = o.w;
                     if (MIS) {
                         mis_area = false;
@@ -660,15 +621,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     // waves in the middle of their arithmetic (-1.5 ms per C3 step on the closest-hit and MIS launches; the
                     // short any-hit steps lose 0.3 ms with it)
                     if (MODE != 1) __builtin_amdgcn_s_setprio(1);
-                    NodePair np;
-                    uint4 ql, qr;
-                    if (FAST) {
-                        const uint4* rec = sc.nodes16 + cur;   // two uint4 per pair, cur = index of the pair's left node
-                        ql = rec[0];
-                        qr = rec[1];
-                    } else {
-                        np = load_pair(sc, cur);
-                    }
+                    const NodePair np = load_pair(sc, cur);
                     if (MODE != 1) {
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_s_setprio(0);
@@ -676,33 +629,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     TCK(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk_bmem += TCK_NOW() - tk_v1;)
                     float dl, dr;
                     bool hl, hr;
-                    uint32_t encl, encr;
-                    if (FAST) {
-                        auto qbox = [&](const uint4 q, float& dist) -> bool {
-#ifdef AGPT_X_NOSDWA
-                            auto cv = [](uint32_t v) { asm volatile("" : "+v"(v)); return (float)v; };
-#else
-                            auto cv = [](uint32_t v) { return (float)v; };
-#endif
-                            const float x0 = __builtin_fmaf(cv(q.x & 0xFFFFu), qA.x, qB0.x), x1 = __builtin_fmaf(cv(q.x >> 16), qA.x, qB1.x);
-                            const float y0 = __builtin_fmaf(cv(q.y & 0xFFFFu), qA.y, qB0.y), y1 = __builtin_fmaf(cv(q.y >> 16), qA.y, qB1.y);
-                            const float z0 = __builtin_fmaf(cv(q.z & 0xFFFFu), qA.z, qB0.z), z1 = __builtin_fmaf(cv(q.z >> 16), qA.z, qB1.z);
-                            const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.f));
-                            const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), rayt));
-                            dist = tmin;
-                            return !(tmax * 1.000002f < tmin);
-                        };
-                        hl = qbox(ql, dl);
-                        hr = qbox(qr, dr);
-                        encl = ql.w;
-                        encr = qr.w;
-                    } else {
-                        encl = __float_as_uint(np.n3.x);
-                        encr = __float_as_uint(np.n3.y);
-                        pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
-                        if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
-                            if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
-                        }
+                    const uint32_t encl = __float_as_uint(np.n3.x), encr = __float_as_uint(np.n3.y);
+                    pair_boxes_fast(np, r, rayt, hl, hr, dl, dr);
+                    if (any_slow) {  // scalar branch: rays with a direction component below 2^-40 (true divisions)
+                        if (!r.fast) pair_boxes_exact(np, r, rayt, hl, hr, dl, dr);
                     }
                     if (COUNT) {
                         if (cur < rootpair_base) c_int++; else c_root++;

@@ -127,13 +127,6 @@ struct DevScene {
     const uint4* toplevel;   // 16-byte nodes, see below
     int32_t n_toplevel;
     const unsigned long long* chunk_mesh_masks;   // mesh_masks[] again, in global memory (per-lane chunk index)
-    // Tolerance mode (agpt_render_params::fast_traversal, off by default): the same trees with 32-byte pair records --
-    // nodes16[2 * pair] = (x, y, z, encoding) of the left node, [2 * pair + 1] of the right one, each coordinate word holding the
-    // box's lower | upper << 16 plane on the 16-bit grid of the mesh's root box (origin = root bmin, step = qscale[prim].xyz),
-    // rounded outward: the quantised box contains the exact one.  Half the bytes and half the vector-memory accesses of an
-    // interior step; the traversal visits a superset of the exact traversal's nodes and tests the same triangles exactly.
-    const uint4* nodes16;
-    const float4* qscale;
     DevCamera cam;
 };
 

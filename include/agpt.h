@@ -114,12 +114,6 @@ typedef struct {
                                    * production path only COUNTS the two kinds of call whose answer cannot reach the image (MIS
                                    * queries whose ray misses the sampled sphere light, the ray after a path's last bounce; see
                                    * agpt_stats::answered_rays): same image bit for bit, same ray totals, less work */
-    int32_t fast_traversal;       /* 1 = TOLERANCE MODE (default 0 = exact).  BVH boxes are read from 32-byte records quantised outward
-                                   * on a 16-bit grid of their mesh's root box and tested conservatively; triangles are tested exactly
-                                   * as always.  The image equals the exact one except where the reference's own rounded box test
-                                   * (bvhtrimesh.h:18-36) prunes a triangle the ray grazes or two hits tie in distance: documented
-                                   * bar >= 99 % of pixels within rel 1e-3 and the image mean within 1e-3 (measured: see DESIGN.md).
-                                   * Applies to scenes of up to 64 primitives rendered without counters; otherwise ignored. */
 } agpt_render_params;
 
 const char* agpt_last_error(void);
