@@ -243,3 +243,48 @@ def test_c3_192_spp_in_mixed_batches():
     assert a.tobytes() == c.tobytes() and sa.rays == sc.rays
     del c
     assert_tiles_match(desc, a, W, H, spp, [(1000, 420, 64, 32)])
+
+
+def test_c4_4k_at_its_256_spp_oracle_tile_and_rank_share():
+    """BASELINE config 4 at its own budget: the C3 scene at 3840x2160 / 256 spp (2.1 G samples, sixteen 128 Mi-path batches of 15-16
+    samples: sample groups of 1 .. 16).  One 64x48 oracle tile pins the film; the last rank's share of the 8-way split at the same
+    budget equals its rows of the full film."""
+    W, H, spp = 3840, 2160, 256
+    desc = ag.scenes.scene_c3()
+    g = gpu_scene(desc)
+    pt = ag.PathTracer(5)
+    full, st = pt.render_to_host(g, W, H, spp)
+    assert st.samples == W * H * spp and st.outliers == 0
+    ctx = g.ctx
+    world, r = 8, 7
+    rows = tiles.local_rows(H, r, world)
+    ptr = ctx.alloc(W * H * 16)
+    ctx.memset(ptr, 0, W * H * 16)
+    pt.render(g, W, H, spp, ptr, interleave=(tiles.BLOCK_ROWS, world, r), want_stats=False)
+    share = ctx.download(ptr, (H, W, 4))[:rows].copy()
+    ctx.free(ptr)
+    g.close()
+    for (y0, h, off) in tiles.row_blocks(H, r, world):
+        assert share[off:off + h].tobytes() == full[H - y0 - h:H - y0].tobytes()
+    assert_tiles_match(desc, full, W, H, spp, [(1800, 1000, 64, 48)])
+
+
+def test_c5_4k_at_its_1024_spp_oracle_tile():
+    """BASELINE config 5 at its own budget: the 5 M-triangle scene at 3840x2160 / 1024 spp = 8.49 G samples -- more than 2^32, so
+    the 32-bit stream index wraps from sample 518 on (agpt_math.h: sample_seed; the oracle indexes the same way).  One 32x32
+    oracle tile at 1024 spp pins the film, wrap included."""
+    W, H, spp = 3840, 2160, 1024
+    desc = ag.scenes.scene_c5()
+    g = gpu_scene(desc)
+    full, st = ag.PathTracer(5).render_to_host(g, W, H, spp)
+    g.close()
+    assert st.samples == W * H * spp
+    o = oracle_scene(desc)
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        tile = (1900, 900, 32, 32)
+        oacc, _ = o.render(W, H, spp, tile=tile, threads=8)
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    a, b = tile_rows(full, H, tile), tile_rows(oacc, H, tile)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
