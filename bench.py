@@ -184,6 +184,14 @@ def roofline_block(sums, cst, rays, steps, workload_key):
     traffic_gbs = traffic_launch / avg_launch_s / 1e9 if traffic_launch and avg_launch_s > 0 else None
     # pair records (child pairs + root pairs) the kernels fetch per second, against the bare gather loop's rate
     g = load_gather_roof()
+    # the vector L1's own counters for the same kernels (tools/gpu_pmc_l1.sh), keyed like the other PMC profiles
+    l1 = None
+    try:
+        cand = json.load(open(os.path.join(ROOT, "profiles", "pmc_r03_%s_l1.json" % workload_key.split(":")[0])))
+        if cand.get("kernel_build") == kernel_build_id() and cand.get("workload") == workload_key:
+            l1 = cand
+    except Exception:  # noqa: BLE001
+        pass
     records_per_ray = (cst.interior_visits + cst.root_tests) / crays
     rec_rate = records_per_ray * rays / trace_s / 1e9 if trace_s > 0 else None
     g_peak = g.get("pair_record_gather_peak_grecords_s") if g else None
@@ -193,7 +201,12 @@ def roofline_block(sums, cst, rays, steps, workload_key):
                                 "chains, 12.8 MB table, 64 active lanes, 5 blocks per CU); %s Grecords/s with 36 active lanes, the interior "
                                 "step's average" % (g.get("pair_record_gather_36_lanes_grecords_s") if g else None),
                    "note": "the kernel's fetches include the coherent top levels of the trees, which coalesce; the microbenchmark's are all "
-                           "divergent -- the fraction says the traversal moves pair records about as fast as a loop that does nothing else"}
+                           "divergent -- the fraction says the traversal moves pair records about as fast as a loop that does nothing else",
+                   "l1_cache_accesses_per_cu_cycle": l1.get("trace_l1_cache_accesses_per_cu_cycle") if l1 else None,
+                   "l1_cache_accesses_per_cu_cycle_by_launch_kind": ({k: v["l1_cache_accesses_per_cu_cycle"] for k, v in l1["kernels"].items()
+                                                                      if k.startswith("trace")} if l1 else None),
+                   "l1_counters_from": ("profiles/pmc_r03_%s_l1.json (TCP_TOTAL_CACHE_ACCESSES / CU-cycles of the trace launches; the L1 takes "
+                                        "about one lane access per cycle)" % workload_key.split(":")[0]) if l1 else None}
     issue_view = {"achieved": round(issue, 1) if issue else None, "peak": ISSUE_PEAK_GINST, "unit": "Gwave-inst/s",
                   "frac": round(issue / ISSUE_PEAK_GINST, 4) if issue else None}
     fracs = {"hbm": traffic_gbs / HBM_PEAK_GBS if traffic_gbs else 0, "l1-gather": gather_view["frac"] or 0, "issue": issue_view["frac"] or 0}
