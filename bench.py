@@ -83,7 +83,7 @@ def load_pmc_profile(workload_key):
             d = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
-        if d.get("kernel_build") == build and d.get("workload") == workload_key:
+        if d.get("kernel_build") == build and d.get("workload") == workload_key and "trace" in d:
             best = d
             best["file"] = os.path.relpath(f, ROOT)
     return best
