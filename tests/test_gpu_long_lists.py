@@ -124,3 +124,40 @@ def test_gpu_long_list_render_is_split_invariant():
     full = tiles.deinterleave(gathered, W, H, world)
     g.close()
     assert np.array_equal(full.view(np.uint32), whole.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_li_batch_on_a_long_list():
+    """agpt_li_batch (single-ray Integrator::Li) through the top-level-tree path: 300 primitives, area light + sky; radiance and the
+    RNG state after each path equal the oracle's PathTracer::Li."""
+    from helpers import gpu_scene, oracle_scene
+    from oracle import binding as ob
+    d = _many_prims(298, 23, duplicates=False)
+    d.add_area_light([0.0, 8.0, 0.0], 0.8, [70, 65, 60])
+    d.add_uniform_infinite_light([.25, .3, .35])
+    d.set_camera([0, 3, -16], [0, 0, 0], [0, 1, 0], 1.5, 50.0, 0.0)
+    assert d.n_prims == 299
+    o = oracle_scene(d, 5)
+    g = gpu_scene(d)
+    rng = np.random.RandomState(11)
+    n = 800
+    rays = np.zeros(n, ag.RAY_DTYPE)
+    states = np.zeros(n, np.uint32)
+    for i in range(n):
+        r, st = o.camera_ray(float(rng.uniform()), float(rng.uniform()), rng=int(rng.randint(1, 2 ** 31 - 1)))
+        rays[i] = r
+        states[i] = st
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        want = np.zeros((n, 3), np.float32)
+        after = np.zeros(n, np.uint32)
+        for i in range(n):
+            L, s_after, _ = o.li(rays[i], int(states[i]))
+            want[i] = L
+            after[i] = s_after
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    got, got_after, _ = ag.PathTracer(5).Li(g, rays, states)
+    g.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got_after, after)
