@@ -1165,8 +1165,8 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             float scatteringPdf = 0;
             v3 wi = V3s(0.f);
             bool light_ok = false;
-            float nee_lightPdf = 0, nee_visT = 0;
-            v3 nee_Li = V3s(0.f), nee_visO = V3s(0.f), nee_visD = V3(0, 0, 1);
+            float nee_lightPdf = 0;
+            v3 nee_Li = V3s(0.f);
             if (do_nee) {
                 int nLights = sc.n_lights;
                 numLight = (int)(rng_float(rng) * nLights);
@@ -1215,9 +1215,15 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                 light_ok = lightPdf > 0 && !isblack(Li);   // integrator.h:44
                 nee_lightPdf = lightPdf;
                 nee_Li = Li;
-                nee_visO = visO;
-                nee_visD = visD;
-                nee_visT = visT;
+                // the shadow ray is written where it is known (it only counts if the path joins the shadow queue below): seven
+                // registers fewer across the three evaluations
+                if (light_ok) {
+                    float4 so4, sd4;
+                    so4.x = visO.x; so4.y = visO.y; so4.z = visO.z; so4.w = visT;
+                    sd4.x = visD.x; sd4.y = visD.y; sd4.z = visD.z; sd4.w = 0.f;
+                    pb.sh_o[pid] = so4;
+                    pb.sh_d[pid] = sd4;
+                }
             }
             SCK(4);   // BSDF set-up + light sampling
             // ---- the three BSDF evaluations of a vertex run through ONE loop with one evaluator call site:
@@ -1291,13 +1297,9 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                     if (!isblack(f)) {
                         float weight = power_heuristic(1, nee_lightPdf, 1, scatteringPdf);
                         v3 c1 = f * nee_Li * weight / nee_lightPdf;
-                        float4 c4, so4, sd4;
+                        float4 c4;
                         c4.x = c1.x; c4.y = c1.y; c4.z = c1.z; c4.w = 0.f;
-                        so4.x = nee_visO.x; so4.y = nee_visO.y; so4.z = nee_visO.z; so4.w = nee_visT;
-                        sd4.x = nee_visD.x; sd4.y = nee_visD.y; sd4.z = nee_visD.z; sd4.w = 0.f;
                         pb.c1[pid] = c4;
-                        pb.sh_o[pid] = so4;
-                        pb.sh_d[pid] = sd4;
                         flags |= PF_PEND_C1;
                         bits |= SB_SHADOW;
                     }
@@ -1396,8 +1398,8 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
     if (bits & SB_EXT) bits |= SB_ACTIVE;
     else if (flags & PF_PENDING) bits |= SB_RESOLVE;
     b4.x = beta.x; b4.y = beta.y; b4.z = beta.z; b4.w = __uint_as_float(flags);
-    l4.x = L.x; l4.y = L.y; l4.z = L.z; l4.w = __uint_as_float(rng);
     pb.beta4[pid] = b4;
+    l4.x = L.x; l4.y = L.y; l4.z = L.z; l4.w = __uint_as_float(rng);
     pb.L4[pid] = l4;
     SCK(6);   // final stores
     return bits;
