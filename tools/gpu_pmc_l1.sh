@@ -16,5 +16,4 @@ run tcp4 TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum
 run tcp5 TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum
 run tcp6 TCP_TCR_TCP_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum
 run tcp7 TCP_TOTAL_ACCESSES_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum
-for f in $O/*_counter_collection.csv; do python3 tools/pmc_agg.py $f | grep -A3 "k_trace_fast<0, 23, false, false, false>" | grep -v "^void\|^--" ; done
-python3 tools/pmc_agg.py $O/grbm_counter_collection.csv | grep "k_trace_fast<0, 23, false, false, false>"
+python3 tools/pmc_l1_json.py $O "c3:1920x1080:64spp:world1:scale1" gpurun_out/pmc_r03_c3_l1.json
