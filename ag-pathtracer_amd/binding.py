@@ -29,7 +29,7 @@ EXPORTS = [
     "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_toplevel_build", "agpt_toplevel_pack16", "agpt_create_backdrop",
     "agpt_intersect_batch", "agpt_intersect_device", "agpt_render", "agpt_li_batch", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
-    "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
+    "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_kat_distribution1d", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
     "agpt_obj_free", "agpt_obj_last_error", "agpt_write_png", "agpt_write_pfm",
     "agpt_comm_unique_id", "agpt_comm_init", "agpt_comm_destroy", "agpt_gather_tiles", "agpt_deinterleave_tiles",
 ]
@@ -129,6 +129,7 @@ def lib():
     L.agpt_kat_bsdf_eval.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
     L.agpt_kat_bsdf_sample.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp, fp, ip]
     L.agpt_kat_rng.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, fp, C.POINTER(C.c_uint32)]
+    L.agpt_kat_distribution1d.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, fp, fp, fp]
     L.agpt_obj_load.argtypes = [C.c_char_p, fp, C.c_int, C.POINTER(vp)]
     L.agpt_obj_parse.argtypes = [C.c_char_p, C.c_size_t, fp, C.c_int, C.POINTER(vp)]
     L.agpt_obj_counts.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
@@ -302,6 +303,19 @@ class Context:
         _check(self.L.agpt_kat_rng(self.h, pixel, wh, sample, seed_base, n, out.ctypes.data_as(C.POINTER(C.c_float)),
                                    C.byref(seed)), "agpt_kat_rng")
         return out, seed.value
+
+    def distribution1d(self, func, u):
+        """Distribution1D(func) and SampleContinuous(u[i]) (sampling.h:19-52): (cdf[n + 1], funcInt, x[k], pdf[k])."""
+        func = np.ascontiguousarray(func, np.float32)
+        u = np.ascontiguousarray(u, np.float32)
+        cdf = np.zeros(func.size + 1, np.float32)
+        x = np.zeros(max(u.size, 1), np.float32)
+        pdf = np.zeros(max(u.size, 1), np.float32)
+        fi = C.c_float(0)
+        P = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        _check(self.L.agpt_kat_distribution1d(self.h, P(func), func.size, P(u), u.size, P(cdf), C.byref(fi), P(x), P(pdf)),
+               "agpt_kat_distribution1d")
+        return cdf, np.float32(fi.value), x[:u.size], pdf[:u.size]
 
     def deinterleave_tiles(self, compact_ptr, W, H, block_rows, world, rank, full_ptr):
         _check(self.L.agpt_deinterleave_tiles(self.h, C.c_void_p(int(compact_ptr)), W, H, block_rows, world, rank, C.c_void_p(int(full_ptr))),

@@ -1128,6 +1128,38 @@ int agpt_kat_rng(agpt_ctx* c, uint32_t pixel, uint32_t wh, uint32_t sample, uint
     return AGPT_OK;
 }
 
+int agpt_kat_distribution1d(agpt_ctx* c, const float* func, int n, const float* u, int k, float* cdf_out, float* func_int_out,
+                            float* x_out, float* pdf_out) {
+    if (!c || !func || n <= 0 || k < 0 || (k && (!u || !x_out || !pdf_out)))
+        return fail(AGPT_ERR_INVALID, "agpt_kat_distribution1d: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float> cdf((size_t)n + 1);
+    const float func_int = agpt::build_distribution1d(func, n, cdf.data());
+    if (cdf_out) memcpy(cdf_out, cdf.data(), 4 * cdf.size());
+    if (func_int_out) *func_int_out = func_int;
+    if (k == 0) return AGPT_OK;
+    TempBuf<float> d_f, d_c, d_u, d_x, d_p;
+    HIP_TRY(d_f.alloc((size_t)n));
+    HIP_TRY(d_c.alloc((size_t)n + 1));
+    HIP_TRY(d_u.alloc((size_t)k));
+    HIP_TRY(d_x.alloc((size_t)k));
+    HIP_TRY(d_p.alloc((size_t)k));
+    HIP_TRY(hipMemcpy(d_f.p, func, 4 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_c.p, cdf.data(), 4 * cdf.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_u.p, u, 4 * (size_t)k, hipMemcpyHostToDevice));
+    DevEnv e{};
+    e.func = d_f.p;
+    e.cdf = d_c.p;
+    e.n = n;
+    e.funcInt = func_int;
+    hipLaunchKernelGGL(k_kat_distribution1d, dim3((k + 63) / 64), dim3(64), 0, c->stream, e, d_u.p, k, d_x.p, d_p.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(x_out, d_x.p, 4 * (size_t)k, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf_out, d_p.p, 4 * (size_t)k, hipMemcpyDeviceToHost));
+    return AGPT_OK;
+}
+
 
 // ---- multi-GPU: gather of the per-rank tile buffers ------------------------------------------------
 // RCCL is bound at run time (dlopen of the librccl already in the process, else the ROCm one): a single-GPU host never

@@ -323,6 +323,20 @@ DevCamera make_camera(const agpt_camera_desc& d) {
     return c;
 }
 
+// Distribution1D ctor (sampling.h:21-33): running sum of func / n, normalised by its last entry (or the uniform ramp when
+// func integrates to 0).  Sequential fp32 sums in this order; returns funcInt.
+float build_distribution1d(const float* func, int n, float* cdf) {
+    cdf[0] = 0;
+    for (int i = 1; i < n + 1; i++) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+    const float func_int = cdf[n];
+    if (func_int == 0) {
+        for (int i = 1; i < n + 1; i++) cdf[i] = float(i) / float(n);
+    } else {
+        for (int i = 1; i < n + 1; i++) cdf[i] /= func_int;
+    }
+    return func_int;
+}
+
 HostEnv make_env(const float* rgb, int width, int height) {
     HostEnv e;
     e.width = width;
@@ -340,14 +354,7 @@ HostEnv make_env(const float* rgb, int width, int height) {
         e.func[idx] = max_component * sinf(th);
     }
     e.cdf.resize((size_t)n + 1);
-    e.cdf[0] = 0;
-    for (int i = 1; i < n + 1; i++) e.cdf[i] = e.cdf[i - 1] + e.func[i - 1] / n;
-    e.funcInt = e.cdf[n];
-    if (e.funcInt == 0) {
-        for (int i = 1; i < n + 1; i++) e.cdf[i] = float(i) / float(n);
-    } else {
-        for (int i = 1; i < n + 1; i++) e.cdf[i] /= e.funcInt;
-    }
+    e.funcInt = build_distribution1d(e.func.data(), n, e.cdf.data());
     return e;
 }
 

@@ -51,6 +51,7 @@ struct HostEnv {
     std::vector<float> func, cdf;
     float funcInt = 0;
 };
+float build_distribution1d(const float* func, int n, float* cdf /*[n + 1]*/);
 HostEnv make_env(const float* rgb, int width, int height);
 
 // BVHTriMesh ctor: Primitive list + BuildRecursive + FlattenBVHTree (bvhtrimesh.h:154-178,213-330)

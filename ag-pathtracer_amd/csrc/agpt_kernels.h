@@ -1638,6 +1638,14 @@ __global__ void k_kat_bsdf_sample(DevScene sc, int material, int n, const float*
     pdfo[i] = pdf;
     speco[i] = spec ? 1 : 0;
 }
+// known-answer kernel: Distribution1D::SampleContinuous (env_sample_continuous) for k draws, one lane each
+__global__ void k_kat_distribution1d(DevEnv e, const float* __restrict__ u, int k, float* __restrict__ x_out, float* __restrict__ pdf_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    float pdf;
+    x_out[i] = env_sample_continuous(e, u[i], &pdf);
+    pdf_out[i] = pdf;
+}
 __global__ void k_kat_rng(uint32_t pixel, uint32_t wh, uint32_t sample, uint32_t seed_base, int n, float* __restrict__ out,
                           uint32_t* __restrict__ seed_out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;

@@ -264,6 +264,11 @@ int agpt_kat_bsdf_sample(agpt_scene*, int material, int n, const float* wo3, con
 /* RNG stream of a (pixel, sample): first n floats (template.cpp:667-675 + cl/tools.cl:1-2) */
 int agpt_kat_rng(agpt_ctx*, uint32_t pixel, uint32_t wh, uint32_t sample, uint32_t seed_base, int n, float* out,
                  uint32_t* seed_out);
+/* Distribution1D (sampling.h:19-69), the importance table of InfiniteAreaLight (lights.cpp:31-48): the ctor on the host
+ * (cdf_out[n + 1], *func_int_out; either may be NULL) and SampleContinuous (:37-52, with FindInterval :4-17) on the device
+ * for k draws u[k] -> x_out[k], pdf_out[k] */
+int agpt_kat_distribution1d(agpt_ctx*, const float* func, int n, const float* u, int k, float* cdf_out, float* func_int_out,
+                            float* x_out, float* pdf_out);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,8 @@ def lib():
     L.oracle_sample_seed.argtypes = [C.c_uint32] * 4
     L.oracle_sample_seed.restype = C.c_uint32
     L.oracle_rng_floats.argtypes = [C.c_uint32, C.c_int, fp, C.POINTER(C.c_uint32)]
+    L.oracle_dist1d_build.argtypes = [fp, C.c_int, fp, fp]
+    L.oracle_dist1d_sample.argtypes = [fp, fp, C.c_float, C.c_int, fp, C.c_int, fp, fp, ip]
     L.oracle_bounds_intersect.argtypes = [fp, fp, C.c_void_p, fp]
     L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]
     L.oracle_bsdf_sample.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, fp, C.POINTER(C.c_int)]
@@ -303,6 +305,22 @@ def rng_floats(seed, n):
     u = np.zeros(n, np.uint32)
     lib().oracle_rng_floats(C.c_uint32(seed), n, f.ctypes.data_as(C.POINTER(C.c_float)), u.ctypes.data_as(C.POINTER(C.c_uint32)))
     return f, u
+
+
+def distribution1d(func, u):
+    """Distribution1D(func) then SampleContinuous(u[i]) (sampling.h:19-52): (cdf[n + 1], funcInt, x[k], pdf[k], offset[k])."""
+    f, pf = _f(func)
+    uu, pu = _f(u)
+    cdf = np.zeros(f.size + 1, np.float32)
+    fi = np.zeros(1, np.float32)
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    lib().oracle_dist1d_build(pf, f.size, P(cdf), P(fi))
+    k = uu.size
+    x = np.zeros(max(k, 1), np.float32)
+    pdf = np.zeros(max(k, 1), np.float32)
+    off = np.zeros(max(k, 1), np.int32)
+    lib().oracle_dist1d_sample(pf, P(cdf), C.c_float(fi[0]), f.size, pu, k, P(x), P(pdf), off.ctypes.data_as(C.POINTER(C.c_int32)))
+    return cdf, fi[0], x[:k], pdf[:k], off[:k]
 
 
 def bounds_intersect(bmin, bmax, ray):

@@ -613,6 +613,21 @@ int oracle_add_uniform_infinite_light(oracle_scene* s, const float L[3]) {
     return s->n_lights - 1;
 }
 
+/* Distribution1D ctor (sampling.h:21-33): cdf[n + 1] and funcInt of the step function func[n] */
+static void dist1d_build(const float* func, int n, float* cdf, float* funcInt) {
+    cdf[0] = 0;
+    for (int i = 1; i < n + 1; i++) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+    *funcInt = cdf[n];
+    if (*funcInt == 0) {
+        for (int i = 1; i < n + 1; i++) cdf[i] = (float)i / (float)n;
+    } else {
+        for (int i = 1; i < n + 1; i++) cdf[i] /= *funcInt;
+    }
+}
+/* known-answer entry points for the Distribution1D restatement (pinned against the reference's own sampling.h compiled in place:
+ * oracle/ref_sampling.cpp, tests/golden/dist1d.npz) */
+void oracle_dist1d_build(const float* func, int n, float* cdf_out, float* funcInt_out) { dist1d_build(func, n, cdf_out, funcInt_out); }
+
 /* InfiniteAreaLight ctor (lights.cpp:31-48, #define ILS on) from an in-memory RGB float image (the reference loads it
  * with stbi_loadf; no .hdr asset ships) + Distribution1D ctor (sampling.h:21-33) */
 int oracle_add_infinite_area_light(oracle_scene* s, const float* rgb, int width, int height) {
@@ -630,14 +645,7 @@ int oracle_add_infinite_area_light(oracle_scene* s, const float* rgb, int width,
     }
     int n = e->n;
     e->cdf = (float*)malloc(sizeof(float) * ((size_t)n + 1));
-    e->cdf[0] = 0;
-    for (int i = 1; i < n + 1; i++) e->cdf[i] = e->cdf[i - 1] + e->func[i - 1] / n;
-    e->funcInt = e->cdf[n];
-    if (e->funcInt == 0) {
-        for (int i = 1; i < n + 1; i++) e->cdf[i] = (float)i / (float)n;
-    } else {
-        for (int i = 1; i < n + 1; i++) e->cdf[i] /= e->funcInt;
-    }
+    dist1d_build(e->func, n, e->cdf, &e->funcInt);
     Light* l = PUSH(s->lights, s->n_lights, Light);
     l->type = LIGHT_INFINITE_AREA; l->shape = -1; l->Lemit = F3s(0.f); l->env = e;
     return s->n_lights - 1;
@@ -1414,6 +1422,18 @@ static float env_sample_continuous(const EnvMap* e, float u, float* pdf) {
     if ((e->cdf[offset + 1] - e->cdf[offset]) > 0) du /= e->cdf[offset + 1] - e->cdf[offset];
     *pdf = (e->funcInt > 0) ? e->func[offset] / e->funcInt : 0;
     return (offset + du) / e->n;
+}
+
+/* Distribution1D::SampleContinuous for k values of u on caller-supplied arrays (known-answer entry point) */
+void oracle_dist1d_sample(const float* func, const float* cdf, float funcInt, int n, const float* u, int k, float* x_out,
+                          float* pdf_out, int* offset_out) {
+    EnvMap e;
+    memset(&e, 0, sizeof(e));
+    e.func = (float*)func; e.cdf = (float*)cdf; e.funcInt = funcInt; e.n = n;
+    for (int i = 0; i < k; i++) {
+        offset_out[i] = env_find_interval(&e, u[i]);
+        x_out[i] = env_sample_continuous(&e, u[i], &pdf_out[i]);
+    }
 }
 
 static f3 light_sample_li(const oracle_scene* s, const Light* l, const SurfaceInteraction* ref, f2 u, f3* wi,

@@ -1,6 +1,8 @@
 """InfiniteAreaLight + Distribution1D + HDRTexture (lights.cpp:31-112, sampling.h, texture.h)
-on the GPU against the oracle.  PARITY UNPINNED against the reference itself: it ships no .hdr asset and no recorded
-output for an environment-lit scene, so the oracle side of this light is a restatement checked only here."""
+on the GPU against the oracle.  Distribution1D is pinned against the reference's own sampling.h (tests/test_dist1d.py);
+the rest of this light (HDRTexture lookup, the spherical mapping of Sample_Li / Pdf_Li / Le) is PARITY UNPINNED against the
+reference itself: it ships no .hdr asset and no recorded output for an environment-lit scene, so the oracle side of those is
+a restatement checked only here."""
 import numpy as np
 import pytest
 
