@@ -5,7 +5,7 @@ the C ABI of include/agpt.h, plus this thin host mirror of the reference's Scene
 """
 from . import build as _build  # noqa: F401
 from .binding import (MAT_DIFFUSE_ONLY, MAT_DISNEY, MAT_MIRROR, AgptError, CameraDesc, Context, PathTracer,  # noqa: F401
-                      RenderParams, Scene, Stats, Comm, comm_unique_id, create_backdrop, bvh_build, toplevel_build, toplevel_pack16, load_obj, lib, library_path, HIT_DTYPE, NODE_DTYPE, RAY_DTYPE,
+                      RenderParams, Scene, Stats, Comm, comm_unique_id, create_backdrop, bvh_build, toplevel_build, toplevel_pack16, load_obj, load_hdr, lib, library_path, HIT_DTYPE, NODE_DTYPE, RAY_DTYPE,
                       EXPORTS)
 from . import scenes  # noqa: F401
 from .scenes import SceneDesc  # noqa: F401

@@ -30,7 +30,7 @@ EXPORTS = [
     "agpt_intersect_batch", "agpt_intersect_device", "agpt_render", "agpt_li_batch", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
     "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_kat_distribution1d", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
-    "agpt_obj_free", "agpt_obj_last_error", "agpt_write_png", "agpt_write_pfm",
+    "agpt_obj_free", "agpt_obj_last_error", "agpt_write_png", "agpt_write_pfm", "agpt_hdr_load", "agpt_hdr_parse", "agpt_hdr_free",
     "agpt_comm_unique_id", "agpt_comm_init", "agpt_comm_destroy", "agpt_gather_tiles", "agpt_deinterleave_tiles",
 ]
 
@@ -143,6 +143,10 @@ def lib():
     L.agpt_gather_tiles.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.agpt_deinterleave_tiles.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.agpt_obj_last_error.restype = C.c_char_p
+    L.agpt_hdr_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(fp)]
+    L.agpt_hdr_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(fp)]
+    L.agpt_hdr_free.argtypes = [fp]
+    L.agpt_hdr_free.restype = None
     _LIB = L
     return L
 
@@ -361,6 +365,23 @@ def write_png(path, rgb_words, width, height):
     a = np.ascontiguousarray(rgb_words, dtype=np.uint32)
     assert a.size == width * height
     _check(lib().agpt_write_png(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_uint32)), width, height), "agpt_write_png")
+
+
+def load_hdr(path=None, data=None):
+    """HDRTexture's pixels (texture.h:41-52: stbi_loadf of a Radiance .hdr) as float32 [H, W, 3], top row first -- from a file
+    or from the file's bytes.  Feed it to Scene.add_infinite_area_light."""
+    L = lib()
+    w, h = C.c_int(0), C.c_int(0)
+    rgb = C.POINTER(C.c_float)()
+    if data is not None:
+        buf = bytes(data)
+        _check(L.agpt_hdr_parse(buf, len(buf), C.byref(w), C.byref(h), C.byref(rgb)), "agpt_hdr_parse")
+    else:
+        _check(L.agpt_hdr_load(os.fsencode(path), C.byref(w), C.byref(h), C.byref(rgb)), "agpt_hdr_load")
+    try:
+        return np.ctypeslib.as_array(rgb, (h.value, w.value, 3)).copy()
+    finally:
+        L.agpt_hdr_free(rgb)
 
 
 def write_pfm(path, accum_host, samples):

@@ -2,6 +2,7 @@
 // C++ host adapter: what MyApp::Init + a few MyApp::Tick calls look like on top of libagpt_hip.so.
 //
 //   g++ -std=c++17 -Iinclude examples/simple_test_scene.cpp -o simple_test_scene ag-pathtracer_amd/libagpt_hip.so
+//   ./simple_test_scene [frames] [environment.hdr]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,7 +28,10 @@ int main(int argc, char** argv) {
         scene.primitives_push_back(backdrop, floor, 1);                    // make_shared<BVHTriMesh>(backdrop, floor, 1)
         scene.primitives_push_back(Sphere{float3{0, 0, 0}, 1.f}, gold);    // make_shared<Sphere>(..., gold)
         scene.addAreaLight(Sphere{float3{0, 25, -20}, 1.f}, float3{200.f, .941f * 200, .914f * 200});
-        scene.lights_push_back(UniformInfiniteLight{float3{.4f, .45f, .5f}});
+        if (argc > 2)   // myapp.cpp:113: scene->lights.push_back(make_shared<InfiniteAreaLight>("small_workshop_1k.hdr"))
+            scene.lights_push_back(InfiniteAreaLight(argv[2]));
+        else
+            scene.lights_push_back(UniformInfiniteLight{float3{.4f, .45f, .5f}});
         scene.camera = CameraDesc{{-1.46f, 1.16f, -4.64f}, {0, 0, 0}, {0, 1, 0}, 1.f, 45.f, 0.f};
         scene.commit();
         PathTracer integrator;  // MaxDepth = 5

@@ -248,6 +248,14 @@ int agpt_resolve(agpt_ctx*, const float* accum_dev, int n_pixels, int samples, u
 int agpt_write_png(const char* path, const uint32_t* rgb, int width, int height);
 int agpt_write_pfm(const char* path, const float* accum_host, int width, int height, int samples);
 
+/* Radiance RGBE (.hdr) reader, host only: what HDRTexture's constructor gets from stbi_loadf(filename, &w, &h, &n, 0)
+ * (texture.h:41-52; the vendored stb_image v2.27, lib/stb_image.h:7005-7215) -- *rgb_out = width*height RGB float32, top row
+ * first, malloc'ed, released with agpt_hdr_free; pass it to agpt_scene_add_infinite_area_light.  Anything that is not a
+ * well-formed Radiance file fails with AGPT_ERR_INVALID (the reference goes on to stb's LDR decoders, or reads past the end). */
+int agpt_hdr_load(const char* path, int* width_out, int* height_out, float** rgb_out);
+int agpt_hdr_parse(const void* bytes, size_t length, int* width_out, int* height_out, float** rgb_out);
+void agpt_hdr_free(float* rgb);
+
 /* device memory helpers for hosts that do not bring their own allocator (tests, the C++ adapter) */
 int agpt_device_alloc(agpt_ctx*, size_t bytes, void** out_dev);
 int agpt_device_free(agpt_ctx*, void* dev);

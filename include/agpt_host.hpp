@@ -14,7 +14,7 @@
 //   make_shared<Sphere>(c, r, mat)                 intersectable.h:161    scene.primitives_push_back(Sphere{c, r}, mat)
 //   scene->addAreaLight(sphere, L)                 scene.h:21        scene.addAreaLight(Sphere{c, r}, L)
 //   scene->lights.push_back(UniformInfiniteLight)  lights.h:37       scene.lights_push_back(UniformInfiniteLight{L})
-//   scene->lights.push_back(InfiniteAreaLight(hdr)) lights.h:53      scene.lights_push_back(InfiniteAreaLight{rgb, w, h})
+//   scene->lights.push_back(InfiniteAreaLight(hdr)) lights.h:53      scene.lights_push_back(InfiniteAreaLight("x.hdr"))
 //   scene->camera = CameraDesc{...}                camera.h:17       scene.camera = ...; (applied at commit)
 //   Scene::Intersect / IntersectP                  scene.h:5-19      scene.Intersect(rays, n, hits) / IntersectP
 //   PathTracer(maxDepth).Li per pixel + Accumulator::AddSample       agpt::PathTracer(maxDepth).Render(scene, accum, spp)
@@ -27,6 +27,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -115,9 +116,21 @@ struct UniformInfiniteLight {
     float3 L;
 };
 // InfiniteAreaLight (lights.h:53-70): the HDR environment map as width*height RGB floats (what stbi_loadf returns)
+// Built from a Radiance .hdr file as in the reference (myapp.cpp:113: InfiniteAreaLight("small_workshop_1k.hdr"); HDRTexture's
+// stbi_loadf, texture.h:41-52 = agpt_hdr_load) or from pixels already in memory.
 struct InfiniteAreaLight {
-    const float* rgb;
-    int width, height;
+    const float* rgb = nullptr;
+    int width = 0, height = 0;
+    InfiniteAreaLight(const float* pixels, int w, int h) : rgb(pixels), width(w), height(h) {}
+    explicit InfiniteAreaLight(const std::string& filename) {
+        float* p = nullptr;
+        check(agpt_hdr_load(filename.c_str(), &width, &height, &p), "agpt_hdr_load");
+        owned_.reset(p, agpt_hdr_free);
+        rgb = p;
+    }
+
+private:
+    std::shared_ptr<float> owned_;
 };
 using CameraDesc = agpt_camera_desc;
 

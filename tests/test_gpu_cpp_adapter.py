@@ -70,6 +70,38 @@ def test_cpp_example_matches_oracle(tmp_path):
     assert int(ml.group(4), 16) == state
 
 
+@pytest.mark.gpu
+def test_cpp_example_lit_by_an_hdr_file_matches_oracle(tmp_path):
+    """The reference's default lighting (myapp.cpp:113): agpt::InfiniteAreaLight("file.hdr") = agpt_hdr_load + the library's
+    Distribution1D, through the C++ adapter; the oracle gets the pixels the vendored stb_image decoded (tests/golden/hdr_cases.npz)."""
+    exe = build_example(tmp_path)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hdr_cases.npz"))
+    hdr = tmp_path / "env.hdr"
+    hdr.write_bytes(g["rle_64x32_sky/bytes"].tobytes())
+    out = subprocess.check_output([exe, "2", str(hdr)]).decode()
+    m = re.search(r"frames=2 rays=(\d+) mean_rgb=([\d.]+) ([\d.]+) ([\d.]+)", out)
+    assert m, out
+    w, h = (int(v) for v in g["rle_64x32_sky/size"])
+    d = ag.SceneDesc("simple_hdr")
+    gold = d.add_material(ag.MAT_DISNEY, [0.944, 0.776, 0.373], .5, 1.)
+    floor = d.add_material(ag.MAT_DISNEY, np.power(np.float32([0xcb, 0xce, 0xb1]) / np.float32(255), np.float32(2.2)), 1., 0.)
+    d.add_mesh(*ag.create_backdrop([0, -1, 20], [40, 20, 40], 7.5, 32), floor, 1)
+    d.add_sphere([0, 0, 0], 1.0, gold)
+    d.add_area_light([0, 25, -20], 1.0, [200., np.float32(.941) * np.float32(200), np.float32(.914) * np.float32(200)])
+    d.add_infinite_area_light(g["rle_64x32_sky/pixels"].view(np.float32).reshape(h, w, 3))
+    d.set_camera([-1.46, 1.16, -4.64], [0, 0, 0], [0, 1, 0], 1.0, 45.0, 0.0)
+    o = oracle_scene(d)
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        acc, st = o.render(256, 256, 2, threads=8)
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    mean = acc[..., :3].astype(np.float64).reshape(-1, 3).sum(0) / (256 * 256) / 2
+    got = np.array([float(m.group(i)) for i in (2, 3, 4)])
+    assert np.allclose(got, mean, rtol=1e-5), (got, mean)
+    assert abs(int(m.group(1)) - st.rays) <= 1e-4 * st.rays
+
+
 def write_obj(path, v, n, idx):
     """Wavefront OBJ with positions, normals and v//vn faces (1-based)."""
     with open(path, "w") as f:
