@@ -85,6 +85,7 @@ struct agpt_ctx {
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
     int blocks_per_cu = 4;       // generic trace kernel (32-entry LDS stacks)
+    int shade_blocks_per_cu = 8;   // AGPT_SHADE_BLOCKS_PER_CU: k_shade's grid (its waves take wave tiles from work heads)
     int fast_blocks_per_cu = AGPT_FAST_BLOCKS_PER_CU;  // AGPT_BLOCKS_PER_CU: production trace kernel (AGPT_FAST_STACK-entry LDS stacks)
     DevBuf<uint32_t> spill;      // traversal-stack entries beyond the LDS part (BVHs deeper than AGPT_FAST_STACK)
     // primitive lists longer than 64 entries: per-path candidate words written by k_candidates, read by k_trace_fast<LIST>
@@ -296,6 +297,7 @@ int agpt_init(int device, agpt_ctx** out) {
     c->force_generic = fg && fg[0] == '1';
     if (const char* mc = getenv("AGPT_MIS_CLOSEST")) c->mis_closest = mc[0] == '1';
     if (const char* bp = getenv("AGPT_BLOCKS_PER_CU")) c->fast_blocks_per_cu = std::max(1, atoi(bp));
+    if (const char* sb = getenv("AGPT_SHADE_BLOCKS_PER_CU")) c->shade_blocks_per_cu = std::min(64, std::max(1, atoi(sb)));
     if (const char* rf = getenv("AGPT_REFILL")) c->refill = std::min(64, std::max(1, atoi(rf)));
     if (const char* rf = getenv("AGPT_REFILL_ANY")) c->refill_any = std::min(64, std::max(1, atoi(rf)));
     *out = c.release();
@@ -721,7 +723,7 @@ struct WavefrontRun {
 static int run_wavefront(agpt_ctx* c, agpt_scene* s, const RenderConsts& rcn, const PathBuffers& pb, Queues q[2], WavefrontRun& run) {
     const int count = run.count;
     const bool mis_mode = run.mis_mode, timing = run.timing;
-    const int shade_grid = c->num_cus * 8;
+    const int shade_grid = c->num_cus * c->shade_blocks_per_cu;
     int cur = 0;
     const int planned = rcn.max_depth + 2;
     for (int it = 0;; it++) {
@@ -734,22 +736,17 @@ static int run_wavefront(agpt_ctx* c, agpt_scene* s, const RenderConsts& rcn, co
         }
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
-        HIP_TRY(hipMemsetAsync(c->work.p, 0, 3 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->work.p, 0, 4 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
         launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
         if (mis_mode)
             launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
         else
             launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
         launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
-        {
-            const dim3 sg(shade_grid), sb(AGPT_BLOCK);
-            if (run.shade_lds_tables && run.shade_env) hipLaunchKernelGGL((k_shade<true, true>), sg, sb, 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
-            else if (run.shade_lds_tables) hipLaunchKernelGGL((k_shade<true, false>), sg, sb, 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
-            else if (run.shade_env) hipLaunchKernelGGL((k_shade<false, true>), sg, sb, 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
-            else hipLaunchKernelGGL((k_shade<false, false>), sg, sb, 0, c->stream, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p);
-        }
+        agpt::launch_shade(c->stream, shade_grid, run.shade_lds_tables, run.shade_env, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p,
+                           c->work.p + 3 * AGPT_FRONTIERS * AGPT_QSTRIDE /* k_shade's tile heads, zeroed above */);
         // (independent of k_shade: different paths)
-        hipLaunchKernelGGL(k_resolve_pending, dim3(c->num_cus * 8), dim3(AGPT_BLOCK), 0, c->stream, s->dev, rcn, pb, q[cur]);
+        agpt::launch_resolve_pending(c->stream, c->num_cus * 8, s->dev, rcn, pb, q[cur]);
         cur = nxt;
         run.iterations++;
         run.launches += 3;
@@ -769,8 +766,7 @@ static void bind_pool(agpt_ctx* c, PathBuffers& pb, Queues q[2]) {
     }
 }
 static bool shade_tables_fit_lds(const DevScene& d) {
-    return d.n_prims <= AGPT_SHADE_LDS_PRIMS && d.n_materials <= AGPT_SHADE_LDS_MATERIALS && d.n_lights <= AGPT_SHADE_LDS_LIGHTS &&
-           !getenv("AGPT_SHADE_GLOBAL_TABLES");
+    return agpt::shade_tables_fit_lds(d.n_prims, d.n_materials, d.n_lights) && !getenv("AGPT_SHADE_GLOBAL_TABLES");
 }
 
 static void read_counters(const DevCounters& d, agpt_stats* st) {

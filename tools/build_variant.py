@@ -11,6 +11,5 @@ b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 tag, extra = sys.argv[1], sys.argv[2:]
 out = os.path.join(b.HERE, "libagpt_hip_%s.so" % tag)
-cmd = ["/opt/rocm/bin/hipcc"] + b.FLAGS + extra + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", out]
-subprocess.check_call(cmd)
+b.build_library(out, extra=extra)
 print(out)

@@ -18,11 +18,15 @@ if "--" in args:
     args, extra = args[:k], args[k + 1:]
 flt = args[0] if args else ""
 flags = [f for f in b.FLAGS if f not in ("-shared", "-fPIC")]
+text = ""
 with tempfile.TemporaryDirectory() as tmp:
-    asm = os.path.join(tmp, "api.s")
-    cmd = ["/opt/rocm/bin/hipcc"] + flags + extra + ["--cuda-device-only", "-S", "-o", asm, os.path.join(b.CSRC, "agpt_api.hip")]
-    subprocess.check_call(cmd)
-    text = open(asm).read()
+    for src in b.SOURCES:
+        if not src.endswith(".hip"):
+            continue
+        asm = os.path.join(tmp, src + ".s")
+        cmd = ["/opt/rocm/bin/hipcc"] + flags + b.SOURCE_FLAGS.get(src, []) + extra + ["--cuda-device-only", "-S", "-o", asm, os.path.join(b.CSRC, src)]
+        subprocess.check_call(cmd)
+        text += open(asm).read() + "\n"
 if os.environ.get("KEEP_ASM"):
     open(os.environ["KEEP_ASM"], "w").write(text)
 demangle = subprocess.run(["c++filt"], input="\n".join(re.findall(r"^\s*\.amdhsa_kernel (\S+)", text, re.M)),
