@@ -34,8 +34,9 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build_library(out, extra=(), verbose=False, objdir=None):
-    """Compile every source to an object with its own flags (in parallel), then link `out`."""
+def build_library(out, extra=(), verbose=False, objdir=None, extra_for=None):
+    """Compile every source to an object with its own flags (in parallel), then link `out`.  extra: flags added for every source;
+    extra_for: {source: flags} added for one (developer A/B builds, tools/build_variant.py)."""
     import concurrent.futures
     import tempfile
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -45,7 +46,7 @@ def build_library(out, extra=(), verbose=False, objdir=None):
         jobs = []
         for src in SOURCES:
             obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
-            jobs.append(([hipcc] + cflags + SOURCE_FLAGS.get(src, []) + list(extra) + ["-c", os.path.join(CSRC, src), "-o", obj], obj))
+            jobs.append(([hipcc] + cflags + SOURCE_FLAGS.get(src, []) + list(extra) + list((extra_for or {}).get(src, [])) + ["-c", os.path.join(CSRC, src), "-o", obj], obj))
         if verbose:
             for cmd, _ in jobs:
                 print(" ".join(cmd))
