@@ -85,6 +85,7 @@ struct agpt_ctx {
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
     int blocks_per_cu = 4;       // generic trace kernel (32-entry LDS stacks)
+    bool trace_small_batch = false;   // the rays of the current batch number fewer than AGPT_SMALL_BATCH: k_trace_fast<PEEK>
     int shade_blocks_per_cu = 8;   // AGPT_SHADE_BLOCKS_PER_CU: k_shade's grid (its waves take wave tiles from work heads)
     int fast_blocks_per_cu = AGPT_FAST_BLOCKS_PER_CU;  // AGPT_BLOCKS_PER_CU: production trace kernel (AGPT_FAST_STACK-entry LDS stacks)
     DevBuf<uint32_t> spill;      // traversal-stack entries beyond the LDS part (BVHs deeper than AGPT_FAST_STACK)
@@ -166,12 +167,13 @@ static bool use_fast_trace(const agpt_ctx* c, const DevScene& sc, int count) {
 
 // LDS stack entries of the production kernel (23 KiB of stack + 8 KiB = 31 KiB per block -> five blocks per CU) and the
 // blocks per CU that go with it; deeper BVHs spill the entries beyond into c->spill (HBM)
-template <int MODE, bool COUNT, bool SPILL>
+#define AGPT_SMALL_BATCH (48ull << 20)   // paths: below this the trace launches run the PEEK instantiation (see k_trace_fast)
+template <int MODE, bool COUNT, bool SPILL, bool PEEK>
 static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* queue, const uint32_t* count_ptr, uint32_t count_imm,
                               uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, int refill) {
     const dim3 block(AGPT_BLOCK), g(fast_grid(c));
     if (sc.n_prims <= 64) {
-        hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, COUNT, SPILL>), g, block, 0, c->stream, sc, queue, count_ptr,
+        hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, COUNT, SPILL, PEEK>), g, block, 0, c->stream, sc, queue, count_ptr,
                            count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0u, c->spill.p,
                            (const unsigned long long*)nullptr, (const uint32_t*)nullptr);
         return;
@@ -185,7 +187,7 @@ static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* q
     }
     hipLaunchKernelGGL((k_candidates<MODE>), dim3(c->num_cus * 8), block, 0, c->stream, sc, queue, count_ptr, count_imm, ro, rd,
                        c->cand_mask.p, c->cand_chunks.p, stride);
-    hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, true, COUNT, SPILL>), g, block, 0, c->stream, sc, queue, count_ptr,
+    hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, true, COUNT, SPILL, PEEK>), g, block, 0, c->stream, sc, queue, count_ptr,
                        count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, stride, c->spill.p,
                        (const unsigned long long*)c->cand_mask.p, (const uint32_t*)c->cand_chunks.p);
 }
@@ -204,11 +206,14 @@ static void launch_trace_fast_c(agpt_ctx* c, int count, const DevScene& sc, cons
         }
     }
     if (count) {
-        if (spill) launch_trace_fast<MODE, true, true>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
-        else launch_trace_fast<MODE, true, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        if (spill) launch_trace_fast<MODE, true, true, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        else launch_trace_fast<MODE, true, false, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+    } else if (c->trace_small_batch) {   // (see PEEK in k_trace_fast)
+        if (spill) launch_trace_fast<MODE, false, true, true>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        else launch_trace_fast<MODE, false, false, true>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
     } else {
-        if (spill) launch_trace_fast<MODE, false, true>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
-        else launch_trace_fast<MODE, false, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        if (spill) launch_trace_fast<MODE, false, true, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
+        else launch_trace_fast<MODE, false, false, false>(c, sc, queue, count_ptr, count_imm, work_head, ro, rd, hits, occ, refill);
     }
 }
 
@@ -724,14 +729,24 @@ static int run_wavefront(agpt_ctx* c, agpt_scene* s, const RenderConsts& rcn, co
     const int count = run.count;
     const bool mis_mode = run.mis_mode, timing = run.timing;
     const int shade_grid = c->num_cus * c->shade_blocks_per_cu;
+    c->trace_small_batch = (unsigned long long)rcn.NP * (unsigned long long)rcn.S < AGPT_SMALL_BATCH;
     int cur = 0;
     const int planned = rcn.max_depth + 2;
     for (int it = 0;; it++) {
         if (it >= planned) {
-            // (active count and, 4 counters further on, the resolve count)
-            HIP_TRY(hipMemcpyAsync(c->host_pinned, q[cur].counts, (4 * AGPT_QSTRIDE + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->host_pinned[0] == 0 && c->host_pinned[4 * AGPT_QSTRIDE] == 0) break;
+            // Termination check, one iteration behind: this iteration's queue counters (active and, 4 counters further on,
+            // resolve) are copied out asynchronously, and what is looked at is the copy made an iteration ago, which has
+            // arrived by now -- the stream never waits for the host (a synchronous check left it idle for ~50 us per iteration,
+            // and the iterations out here are a few hundred microseconds long).  The price is one iteration of launches over
+            // empty queues at the very end (the kernels return at once on those).
+            uint32_t* slot = c->host_pinned + (it & 1) * (AGPT_NQUEUES * AGPT_QSTRIDE);
+            HIP_TRY(hipMemcpyAsync(slot, q[cur].counts, (4 * AGPT_QSTRIDE + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->ev[2 + (it & 1)], c->stream));
+            if (it > planned) {
+                const uint32_t* seen = c->host_pinned + ((it - 1) & 1) * (AGPT_NQUEUES * AGPT_QSTRIDE);
+                HIP_TRY(hipEventSynchronize(c->ev[2 + ((it - 1) & 1)]));
+                if (seen[0] == 0 && seen[4 * AGPT_QSTRIDE] == 0) break;
+            }
             if (it > 4096) return fail(AGPT_ERR_LIMIT, "agpt: path did not terminate");
         }
         const int nxt = cur ^ 1;
@@ -797,6 +812,7 @@ int agpt_intersect_device(agpt_scene* s, const agpt_ray* d_rays, int n, agpt_hit
     // stats requested -> the instrumented reference-order kernel (work counters); AGPT_INTERSECT_TIMING=1 (developer knob)
     // keeps the production kernel so that stats->trace_ms times it
     const int instrumented = (stats != nullptr && !getenv("AGPT_INTERSECT_TIMING")) ? 1 : 0;
+    c->trace_small_batch = (unsigned long long)n < AGPT_SMALL_BATCH;
     if (any_hit)
         launch_trace<1>(c, s->dev, nullptr, nullptr, (uint32_t)n, c->work.p, c->ext_o.p, c->ext_d.p, c->hit.p, c->occluded.p,
                         instrumented);

@@ -117,7 +117,7 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 #ifndef AGPT_TRACE_WAVES
 #define AGPT_TRACE_WAVES 1   // minimum waves per SIMD the register allocation of k_trace_fast is held to
 #endif
-template <int MODE, int DEPTH, bool LIST, bool COUNT, bool SPILL>
+template <int MODE, int DEPTH, bool LIST, bool COUNT, bool SPILL, bool PEEK>
 __global__ void __launch_bounds__(AGPT_BLOCK, AGPT_TRACE_WAVES)
 k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
@@ -147,6 +147,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // (a value loaded through a pointer counts as divergent for the compiler: readfirstlane keeps the bookkeeping scalar)
     const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)(count_ptr ? *count_ptr : count_imm));
+    // (the late iterations' queues are short or empty: a launch can use one wave per 64 rays -- the rest of the grid leaves
+    // before setting up, with nothing to drain)
+    if (blockIdx.x * (uint32_t)BLOCK >= count) return;
     const int n_prims = LIST ? 0 : sc.n_prims;   // (short lists: the primitive records live in LDS)
     if (PRIM_LDS && (int)threadIdx.x < n_prims) {
         const DevPrim& P = sc.prims[threadIdx.x];
@@ -376,6 +379,24 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             if (!in_range && segs_left > 0) {
                 --segs_left;
                 seg = (seg + 1u) & (AGPT_FRONTIERS - 1u);
+                // PEEK (launches over small batches, e.g. a rank's share of a split film): segments that other waves have drained
+                // meanwhile are skipped after ONE look at all the frontiers (lane k reads frontier k, past the L1) instead of one
+                // failing atomic each.  At the end of a launch every wave of the grid walks through all eight segments -- 5,120 x 8
+                // same-line atomics at ~11 ns, ~56 us during which the launch only drains: 2.4 % of a rank's step at an 8-way
+                // split of the 1080p film, 3.4 % at a 4-way one.  A frontier only grows: a stale value costs an atomic, never a
+                // ray.  Not in the instantiation for full-size batches: the code costs the hot loop two registers and 1 ms per
+                // 1080p/64spp step, more than the drain it saves there.
+                if (PEEK && segs_left > 0) {
+                    uint32_t head = 0;
+                    if (lane < (int)AGPT_FRONTIERS) head = __hip_atomic_load(work_head + lane * AGPT_QSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t fb = (uint32_t)lane * seg_len;
+                    const bool live = lane < (int)AGPT_FRONTIERS && fb < count && head < (count - fb < seg_len ? count - fb : seg_len);
+                    const uint32_t live_mask = (uint32_t)__ballot(live);
+                    while (segs_left > 0 && !((live_mask >> seg) & 1u)) {
+                        --segs_left;
+                        seg = (seg + 1u) & (AGPT_FRONTIERS - 1u);
+                    }
+                }
             }
         }
         // (2) ... then the new loads, back to back, with no use of a loaded value in between: a merge of branches with

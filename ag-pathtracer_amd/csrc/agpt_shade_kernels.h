@@ -423,6 +423,8 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
     __shared__ DevPrim s_tab_prims[LDS_TABLES ? AGPT_SHADE_LDS_PRIMS : 1];
     __shared__ DevMaterial s_tab_materials[LDS_TABLES ? AGPT_SHADE_LDS_MATERIALS : 1];
     __shared__ DevLight s_tab_lights[LDS_TABLES ? AGPT_SHADE_LDS_LIGHTS : 1];
+    // (a launch over a short queue: one wave per 256-path tile is all it can use -- the rest of the grid leaves before setting up)
+    if (blockIdx.x * (AGPT_BLOCK / 64) * 64u * SHADE_U >= QCOUNT(qin, 0) && blockIdx.x > 0) return;
     DevScene sc = sc_in;
     if (LDS_TABLES) {
         auto copy_words = [&](void* dst, const void* src, int n_bytes) {
@@ -481,6 +483,21 @@ k_shade(DevScene sc_in, RenderConsts rc, PathBuffers pb, Queues qin, Queues qout
             }
             seg = (seg + 1u) & (AGPT_FRONTIERS - 1u);
             --segs_left;
+            // segments that other waves have drained meanwhile are skipped after one look at all the heads (lane k reads head k,
+            // past the L1) instead of one failing atomic each: without it every wave of the grid ends with a walk through all
+            // eight -- 8,192 x 8 same-line atomics at ~11 ns, ~90 us in which the launch only drains.  A head only grows: a stale
+            // value costs an atomic, never a tile.
+            if (segs_left) {
+                uint32_t head = 0;
+                if (lane < (int)AGPT_FRONTIERS) head = __hip_atomic_load(tile_heads + lane * AGPT_QSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t fb = (uint32_t)lane * seg_tiles;
+                const bool live = lane < (int)AGPT_FRONTIERS && fb < n_wtiles && head < min(seg_tiles, n_wtiles - fb);
+                const uint32_t live_mask = (uint32_t)__ballot(live);
+                while (segs_left && !((live_mask >> seg) & 1u)) {
+                    seg = (seg + 1u) & (AGPT_FRONTIERS - 1u);
+                    --segs_left;
+                }
+            }
         }
         return false;
     };
