@@ -85,6 +85,7 @@ struct agpt_ctx {
     DevBuf<DevCounters> counters;
     uint32_t* host_pinned = nullptr;
     int blocks_per_cu = 4;       // generic trace kernel (32-entry LDS stacks)
+    bool trace_recast = false;        // the closest-hit launch in flight is the wavefront loop's own (its rays carry d.w, see k_trace_fast)
     bool trace_small_batch = false;   // the rays of the current batch number fewer than AGPT_SMALL_BATCH: k_trace_fast<PEEK>
     int shade_blocks_per_cu = 8;   // AGPT_SHADE_BLOCKS_PER_CU: k_shade's grid (its waves take wave tiles from work heads)
     int fast_blocks_per_cu = AGPT_FAST_BLOCKS_PER_CU;  // AGPT_BLOCKS_PER_CU: production trace kernel (AGPT_FAST_STACK-entry LDS stacks)
@@ -173,9 +174,12 @@ static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* q
                               uint32_t* work_head, const float4* ro, const float4* rd, DevHit* hits, uint32_t* occ, int refill) {
     const dim3 block(AGPT_BLOCK), g(fast_grid(c));
     if (sc.n_prims <= 64) {
+        // (closest-hit launches of the wavefront loop may re-cast a ray in place: see the retire branch of k_trace_fast)
+        float4* ro_w = MODE == 0 && c->trace_recast ? const_cast<float4*>(ro) : nullptr;
+        float4* rd_w = MODE == 0 && c->trace_recast ? const_cast<float4*>(rd) : nullptr;
         hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, COUNT, SPILL, PEEK>), g, block, 0, c->stream, sc, queue, count_ptr,
                            count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0u, c->spill.p,
-                           (const unsigned long long*)nullptr, (const uint32_t*)nullptr);
+                           (const unsigned long long*)nullptr, (const uint32_t*)nullptr, ro_w, rd_w);
         return;
     }
     // more than 64 primitives: the top-level tree gives every ray its candidates (one word per chunk of 64 primitives), then
@@ -189,7 +193,7 @@ static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* q
                        c->cand_mask.p, c->cand_chunks.p, stride);
     hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, true, COUNT, SPILL, PEEK>), g, block, 0, c->stream, sc, queue, count_ptr,
                        count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, stride, c->spill.p,
-                       (const unsigned long long*)c->cand_mask.p, (const uint32_t*)c->cand_chunks.p);
+                       (const unsigned long long*)c->cand_mask.p, (const uint32_t*)c->cand_chunks.p, (float4*)nullptr, (float4*)nullptr);
 }
 
 template <int MODE>
@@ -752,7 +756,9 @@ static int run_wavefront(agpt_ctx* c, agpt_scene* s, const RenderConsts& rcn, co
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
         HIP_TRY(hipMemsetAsync(c->work.p, 0, 4 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
+        c->trace_recast = !getenv("AGPT_NO_RECAST");
         launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
+        c->trace_recast = false;
         if (mis_mode)
             launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
         else

@@ -123,7 +123,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
              DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters, int refill,
              uint32_t cand_stride, uint32_t* __restrict__ spill, const unsigned long long* __restrict__ cand_mask,
-             const uint32_t* __restrict__ cand_chunks) {
+             const uint32_t* __restrict__ cand_chunks, float4* ray_o_w, float4* ray_d_w) {
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
     constexpr int BLOCK = AGPT_BLOCK;
@@ -156,10 +156,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         float4 a, b;
         if (P.type == AGPT_PRIM_SPHERE) {
             a.x = P.cx; a.y = P.cy; a.z = P.cz; a.w = 1.f;
-            b.x = P.r2; b.y = 0.f; b.z = 0.f; b.w = 0.f;
+            b.x = P.r2; b.y = 0.f; b.z = P.material < 0 ? 1.f : 0.f; b.w = 0.f;   // b.z: no material (an emitter's sphere)
         } else if (P.type == AGPT_PRIM_PLANE) {
             a.x = P.cx; a.y = P.cy; a.z = P.cz; a.w = 3.f;
-            b.x = P.r; b.y = P.r2; b.z = 0.f; b.w = 0.f;
+            b.x = P.r; b.y = P.r2; b.z = P.material < 0 ? 1.f : 0.f; b.w = 0.f;
         } else {
             a.x = P.root_bmin[0]; a.y = P.root_bmin[1]; a.z = P.root_bmin[2]; a.w = P.n_tris > 0 ? 0.f : 2.f;
             b.x = P.root_bmax[0]; b.y = P.root_bmax[1]; b.z = P.root_bmax[2]; b.w = __uint_as_float(P.root_enc);
@@ -601,19 +601,53 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
             } else if (cur == CUR_PICK) {
                 // end of the primitive list (retire), or the sphere / plane that is next in list order
                 if (mask == 0) {
+                    bool recast = false;
                     if (MIS) {
                         occluded[pid] = mis_reach ? 1u : 0u;
                     } else if (ANY) {
                         occluded[pid] = 0u;
                     } else {
-                        DevHit h;
-                        h.t = rayt;
-                        h.id = hid;
-                        h.b1 = hb1;
-                        h.b2 = hb2;
-                        hits[pid] = h;
+                        // A closest hit on a primitive without a material (an emitter's sphere), on a ray whose next vertex
+                        // would do nothing but re-cast it (d.w = 1, set by k_shade): integrator.h:152-161's re-cast is made here,
+                        // on the spot, in k_shade's arithmetic -- the path is spared an iteration of five launches for it, and the
+                        // render the trail of near-empty iterations such paths used to leave (4 ms of a 1080p/64spp step).  The
+                        // new ray is a Scene::Intersect call of its own (counted), walks every primitive of the list, and k_shade
+                        // finds it in ext_o / ext_d.  Rays whose re-cast needs the true-division slab test are left to k_shade.
+                        if (!LIST && ray_o_w && hid != AGPT_HIT_MISS && (hid & AGPT_HIT_SPHERE)) {
+                            if (s_prim[2 * (hid & 0x7FFFFFFFu) + 1].z != 0.f && ray_d_w[pid].w != 0.f) {
+                                const v3 p = r.O + rayt * r.D;
+                                const v3 nO = p + AGPT_EPSILON * r.D;
+                                const v3 nD = normalize(r.D);
+                                const TraceRay nr = make_trace_ray(nO, nD);
+                                if (nr.fast) {
+                                    float4 no4, nd4;
+                                    no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
+                                    nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 1.f;
+                                    ray_o_w[pid] = no4;
+                                    ray_d_w[pid] = nd4;
+                                    atomicAdd(&counters->closest_rays, 1ull);
+                                    r = nr;
+                                    rayt = AGPT_FLT_MAX;
+                                    hid = AGPT_HIT_MISS;
+                                    hb1 = 0.f;
+                                    hb2 = 0.f;
+                                    sp = 0;
+                                    mask = all_prims;
+                                    cur = pick_next(mask);
+                                    recast = true;
+                                }
+                            }
+                        }
+                        if (!recast) {
+                            DevHit h;
+                            h.t = rayt;
+                            h.id = hid;
+                            h.b1 = hb1;
+                            h.b2 = hb2;
+                            hits[pid] = h;
+                        }
                     }
-                    cur = CUR_IDLE;
+                    if (!recast) cur = CUR_IDLE;
                 } else {
                     const int k = (LIST ? 64 * (int)(cinfo >> 16) : 0) + __ffsll((long long)mask) - 1;   // list index
                     mask &= mask - 1;

@@ -134,7 +134,8 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             v3 nD = normalize(D);
             float4 no4, nd4;
             no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
-            nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
+            nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z;
+            nd4.w = (bounces > 0 && !(flags & PF_SPECULAR)) ? 1.f : 0.f;   // (see below: the trace kernel may re-cast again itself)
             pb.ext_o[pid] = no4;
             pb.ext_d[pid] = nd4;
             bits |= SB_EXT;
@@ -364,7 +365,12 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
                         v3 nD = normalize(wi);
                         float4 no4, nd4;
                         no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
-                        nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 0.f;
+                        nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z;
+                        // d.w = 1: should this ray's closest hit be a primitive without a material (an emitter sphere), the next
+                        // vertex does nothing but re-cast it (no emission after a non-specular bounce, :139-147; below maxDepth,
+                        // :150; no bounce counted, :152-161) -- k_trace_fast may then do that re-cast itself instead of sending the
+                        // path through a whole iteration for it
+                        nd4.w = (!sampledSpecular && (int)(bounces + 1) < rc.max_depth) ? 1.f : 0.f;
                         pb.ext_o[pid] = no4;
                         pb.ext_d[pid] = nd4;
                         bits |= SB_EXT;

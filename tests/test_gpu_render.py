@@ -170,3 +170,42 @@ def test_sample_bundle_splits_agree():
         assert tiles.deinterleave(bufs, W, H, 2).tobytes() == full.tobytes()
         ctx.free(ptr)
     g.close()
+
+
+def emitter_gauntlet():
+    """C1's geometry with six emitter spheres of different sizes hovering just above the floor around the gold sphere, two of them
+    overlapping: bounce rays cross one, two or three emitters (entering and leaving each is a re-cast of its own,
+    integrator.h:152-161), some start inside one."""
+    d = ag.scenes.scene_c1()
+    d.name = "emitter-gauntlet"
+    for c, r in (([1.6, -0.2, 0.4], 0.7), ([2.2, -0.1, 0.9], 0.6), ([-1.8, -0.3, 0.8], 0.6), ([0.2, -0.4, -1.9], 0.5),
+                 ([0.0, 1.9, 0.3], 0.5), ([-0.6, -0.5, 2.4], 0.45)):
+        d.add_area_light(c, r, ag.scenes.KEY_LIGHT * np.float32(3))
+    return d
+
+
+def test_emitter_pass_through_recast_in_the_trace_kernel(monkeypatch):
+    """A ray whose closest hit is a primitive without a material is re-cast by k_trace_fast itself where the next vertex would do
+    nothing else (ext_d.w = 1): same image, same ray counts as the oracle and as the flow that sends the path through k_shade
+    for it (AGPT_NO_RECAST=1), in fewer wavefront iterations."""
+    d = emitter_gauntlet()
+    compare(d, 96, 96, 4)                       # instrumented kernels (k_shade re-casts) == production kernels == oracle
+    g = gpu_scene(d)
+    pt = ag.PathTracer(5)
+    a, sa = pt.render_to_host(g, 160, 120, 8)
+    monkeypatch.setenv("AGPT_NO_RECAST", "1")
+    b, sb = pt.render_to_host(g, 160, 120, 8)
+    monkeypatch.delenv("AGPT_NO_RECAST")
+    g.close()
+    assert a.tobytes() == b.tobytes()
+    assert (sa.rays, sa.closest_rays, sa.anyhit_rays, sa.shaded_vertices) == (sb.rays, sb.closest_rays, sb.anyhit_rays, sb.shaded_vertices)
+    print("iterations with the in-kernel re-cast %d, without %d" % (sa.iterations, sb.iterations))
+    assert sa.iterations < sb.iterations
+    o = oracle_scene(d, 5)
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        oacc, ost = o.render(160, 120, 8, rng_mode=ob.RNG_PER_SAMPLE, threads=8)
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    assert np.array_equal(a[..., :3].view(np.uint32), oacc[..., :3].view(np.uint32))
+    assert sa.rays == ost.rays
