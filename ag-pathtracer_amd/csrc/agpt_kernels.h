@@ -180,7 +180,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     // up and the next chunk's word has to be fetched.
     uint32_t pid = 0;
     unsigned long long mask = 0;
-    constexpr uint32_t CUR_IDLE = 0x7FFFFFFFu, CUR_PICK = 0x7FFFFFFEu, CUR_FETCH = 0x7FFFFFFDu;
+    // CUR_RECAST (closest-hit launches of the wavefront loop): the ray has retired on a primitive without a material and waits for
+    // the top of the outer loop to be re-cast (see there); it takes part in no vote.
+    constexpr uint32_t CUR_IDLE = 0x7FFFFFFFu, CUR_RECAST = 0x7FFFFFFEu, CUR_PICK = 0x7FFFFFFDu, CUR_FETCH = 0x7FFFFFFCu;
     constexpr uint32_t CUR_B_END = LIST ? CUR_FETCH : CUR_PICK;   // state B: cur < CUR_B_END
     const uint32_t rootpair_base = sc.rootpair_base;
     const unsigned long long mesh_mask0 = sc.mesh_masks[0];
@@ -433,6 +435,45 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
         TCK(const unsigned long long tk_r0 = TCK_NOW();)
         pin_state();
         any_slow = uni(any_slow);
+        // ---- parked lanes: emitter pass-through ----------------------------------------------------------------
+        // integrator.h:152-161's re-cast of a ray that has hit a primitive without a material, made here, on the spot, in
+        // k_shade's arithmetic, where the next vertex would do nothing else: the path is spared an iteration of five launches for
+        // it, and the render the trail of near-empty iterations such paths used to leave (4 ms of a 1080p/64spp step).  The new
+        // ray is a Scene::Intersect call of its own (counted), walks every primitive of the list, and k_shade finds it in
+        // ext_o / ext_d.  A re-cast that would need the true-division slab test is left to k_shade: the hit is written after all.
+        // (Out here, not in the retire branch of the vote loop, where the same code cost the loop four registers and 1 ms.)
+        if (MODE == 0 && !LIST && __ballot(cur == CUR_RECAST) != 0) {
+            if (cur == CUR_RECAST) {
+                const v3 p = r.O + rayt * r.D;
+                const v3 nO = p + AGPT_EPSILON * r.D;
+                const v3 nD = normalize(r.D);
+                const TraceRay nr = make_trace_ray(nO, nD);
+                if (nr.fast) {
+                    float4 no4, nd4;
+                    no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
+                    nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 1.f;
+                    ray_o_w[pid] = no4;
+                    ray_d_w[pid] = nd4;
+                    atomicAdd(&counters->closest_rays, 1ull);
+                    r = nr;
+                    rayt = AGPT_FLT_MAX;
+                    hid = AGPT_HIT_MISS;
+                    hb1 = 0.f;
+                    hb2 = 0.f;
+                    sp = 0;
+                    mask = all_prims;
+                    cur = pick_next(mask);
+                } else {
+                    DevHit h;
+                    h.t = rayt;
+                    h.id = hid;
+                    h.b1 = hb1;
+                    h.b2 = hb2;
+                    hits[pid] = h;
+                    cur = CUR_IDLE;
+                }
+            }
+        }
         // ---- refill ---------------------------------------------------------------------------------------
         unsigned long long act = __ballot(cur != CUR_IDLE);
         const int n_active0 = __popcll(act);
@@ -607,37 +648,11 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     } else if (ANY) {
                         occluded[pid] = 0u;
                     } else {
-                        // A closest hit on a primitive without a material (an emitter's sphere), on a ray whose next vertex
-                        // would do nothing but re-cast it (d.w = 1, set by k_shade): integrator.h:152-161's re-cast is made here,
-                        // on the spot, in k_shade's arithmetic -- the path is spared an iteration of five launches for it, and the
-                        // render the trail of near-empty iterations such paths used to leave (4 ms of a 1080p/64spp step).  The
-                        // new ray is a Scene::Intersect call of its own (counted), walks every primitive of the list, and k_shade
-                        // finds it in ext_o / ext_d.  Rays whose re-cast needs the true-division slab test are left to k_shade.
-                        if (!LIST && ray_o_w && hid != AGPT_HIT_MISS && (hid & AGPT_HIT_SPHERE)) {
-                            if (s_prim[2 * (hid & 0x7FFFFFFFu) + 1].z != 0.f && ray_d_w[pid].w != 0.f) {
-                                const v3 p = r.O + rayt * r.D;
-                                const v3 nO = p + AGPT_EPSILON * r.D;
-                                const v3 nD = normalize(r.D);
-                                const TraceRay nr = make_trace_ray(nO, nD);
-                                if (nr.fast) {
-                                    float4 no4, nd4;
-                                    no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
-                                    nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 1.f;
-                                    ray_o_w[pid] = no4;
-                                    ray_d_w[pid] = nd4;
-                                    atomicAdd(&counters->closest_rays, 1ull);
-                                    r = nr;
-                                    rayt = AGPT_FLT_MAX;
-                                    hid = AGPT_HIT_MISS;
-                                    hb1 = 0.f;
-                                    hb2 = 0.f;
-                                    sp = 0;
-                                    mask = all_prims;
-                                    cur = pick_next(mask);
-                                    recast = true;
-                                }
-                            }
-                        }
+                        // A closest hit on a primitive without a material (an emitter's sphere), on a ray whose next vertex would
+                        // do nothing but re-cast it (d.w = 1, set by k_shade): the lane is parked for the re-cast at the top of the
+                        // outer loop instead of retiring.
+                        if (!LIST && ray_o_w && hid != AGPT_HIT_MISS && (hid & AGPT_HIT_SPHERE))
+                            recast = s_prim[2 * (hid & 0x7FFFFFFFu) + 1].z != 0.f && ray_d_w[pid].w != 0.f;
                         if (!recast) {
                             DevHit h;
                             h.t = rayt;
@@ -647,7 +662,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                             hits[pid] = h;
                         }
                     }
-                    if (!recast) cur = CUR_IDLE;
+                    cur = recast ? CUR_RECAST : CUR_IDLE;
                 } else {
                     const int k = (LIST ? 64 * (int)(cinfo >> 16) : 0) + __ffsll((long long)mask) - 1;   // list index
                     mask &= mask - 1;
