@@ -179,7 +179,7 @@ static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* q
         float4* rd_w = MODE == 0 && c->trace_recast ? const_cast<float4*>(rd) : nullptr;
         hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, false, COUNT, SPILL, PEEK>), g, block, 0, c->stream, sc, queue, count_ptr,
                            count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, 0u, c->spill.p,
-                           (const unsigned long long*)nullptr, (const uint32_t*)nullptr, ro_w, rd_w);
+                           (const unsigned long long*)nullptr, (const uint32_t*)nullptr, ro_w, rd_w, (const float4*)c->beta4.p, c->L4.p);
         return;
     }
     // more than 64 primitives: the top-level tree gives every ray its candidates (one word per chunk of 64 primitives), then
@@ -193,7 +193,8 @@ static void launch_trace_fast(agpt_ctx* c, const DevScene& sc, const uint32_t* q
                        c->cand_mask.p, c->cand_chunks.p, stride);
     hipLaunchKernelGGL((k_trace_fast<MODE, AGPT_FAST_STACK, true, COUNT, SPILL, PEEK>), g, block, 0, c->stream, sc, queue, count_ptr,
                        count_imm, work_head, ro, rd, hits, occ, c->counters.p, refill, stride, c->spill.p,
-                       (const unsigned long long*)c->cand_mask.p, (const uint32_t*)c->cand_chunks.p, (float4*)nullptr, (float4*)nullptr);
+                       (const unsigned long long*)c->cand_mask.p, (const uint32_t*)c->cand_chunks.p, (float4*)nullptr, (float4*)nullptr,
+                       (const float4*)nullptr, (float4*)nullptr);
 }
 
 template <int MODE>
@@ -1045,7 +1046,7 @@ int agpt_li_batch(agpt_scene* s, const agpt_ray* rays, const uint32_t* rng_state
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const dim3 grid((unsigned)((n + AGPT_BLOCK - 1) / AGPT_BLOCK)), block(AGPT_BLOCK);
-    hipLaunchKernelGGL(k_generate_li, grid, block, 0, c->stream, (const agpt_ray*)d_rays.p, (const uint32_t*)d_rng.p, (uint32_t)n, pb, q[0]);
+    hipLaunchKernelGGL(k_generate_li, grid, block, 0, c->stream, (const agpt_ray*)d_rays.p, (const uint32_t*)d_rng.p, (uint32_t)n, pb, q[0], max_depth);
     rc = run_wavefront(c, s, rcn, pb, q, run);
     if (rc) return rc;
     hipLaunchKernelGGL(k_export_li, grid, block, 0, c->stream, pb, (uint32_t)n, d_out.p, rng_states_out ? d_rng.p : (uint32_t*)nullptr);

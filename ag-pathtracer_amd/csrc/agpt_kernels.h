@@ -123,7 +123,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
              uint32_t* __restrict__ work_head, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
              DevHit* __restrict__ hits, uint32_t* __restrict__ occluded, DevCounters* __restrict__ counters, int refill,
              uint32_t cand_stride, uint32_t* __restrict__ spill, const unsigned long long* __restrict__ cand_mask,
-             const uint32_t* __restrict__ cand_chunks, float4* ray_o_w, float4* ray_d_w) {
+             const uint32_t* __restrict__ cand_chunks, float4* ray_o_w, float4* ray_d_w, const float4* path_beta4, float4* path_L4) {
     constexpr bool ANY = MODE != 0;
     constexpr bool MIS = MODE == 2;
     constexpr int BLOCK = AGPT_BLOCK;
@@ -449,9 +449,21 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                 const v3 nD = normalize(r.D);
                 const TraceRay nr = make_trace_ray(nO, nD);
                 if (nr.fast) {
+                    const float kind = ray_d_w[pid].w;
+                    if (kind == 2.f) {
+                        // a camera ray (d.w = 2): the vertex first adds the emitter's radiance (integrator.h:139-147, bounces == 0;
+                        // nothing of an earlier vertex is pending on it), then re-casts
+                        const int al = sc.prims[hid & 0x7FFFFFFFu].arealight;
+                        const v3 Le = al >= 0 ? V3(sc.lights[al].L[0], sc.lights[al].L[1], sc.lights[al].L[2]) : V3s(0.f);
+                        const float4 b4 = path_beta4[pid];
+                        float4 l4 = path_L4[pid];
+                        const v3 L = V3(l4.x, l4.y, l4.z) + V3(b4.x, b4.y, b4.z) * Le;
+                        l4.x = L.x; l4.y = L.y; l4.z = L.z;
+                        path_L4[pid] = l4;
+                    }
                     float4 no4, nd4;
                     no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
-                    nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = 1.f;
+                    nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z; nd4.w = kind;
                     ray_o_w[pid] = no4;
                     ray_d_w[pid] = nd4;
                     atomicAdd(&counters->closest_rays, 1ull);
@@ -915,7 +927,8 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
     v3 D = normalize(pixel - c.origin - offset);
     float4 o4, d4, b4, l4;
     o4.x = O.x; o4.y = O.y; o4.z = O.z; o4.w = AGPT_FLT_MAX;
-    d4.x = D.x; d4.y = D.y; d4.z = D.z; d4.w = 0.f;
+    d4.x = D.x; d4.y = D.y; d4.z = D.z;
+    d4.w = rc.max_depth > 0 ? 2.f : 0.f;   // 2: a camera ray that may be re-cast through emitters by the trace kernel (see k_trace_fast)
     b4.x = 1.f; b4.y = 1.f; b4.z = 1.f; b4.w = __uint_as_float(0u);
     l4.x = 0.f; l4.y = 0.f; l4.z = 0.f; l4.w = __uint_as_float(rng);
     pb.ext_o[i] = o4;
@@ -936,14 +949,15 @@ k_generate(DevScene sc, RenderConsts rc, PathBuffers pb, Queues q) {
 // agpt_li_batch: Integrator::Li(ray, scene) (integrator.h:28-31) for n caller-supplied rays, each with its own RandomFloat() stream
 // (an xorshift32 state, template/template.cpp:667-675).  The Ray ctor normalises D (camera.h:6); ray.t is the caller's tmax.
 __global__ void __launch_bounds__(AGPT_BLOCK)
-k_generate_li(const agpt_ray* __restrict__ rays, const uint32_t* __restrict__ rng_states, uint32_t n, PathBuffers pb, Queues q) {
+k_generate_li(const agpt_ray* __restrict__ rays, const uint32_t* __restrict__ rng_states, uint32_t n, PathBuffers pb, Queues q, int max_depth) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const agpt_ray r = rays[i];
     const v3 d = normalize(V3(r.d[0], r.d[1], r.d[2]));
     float4 o4, d4, b4, l4;
     o4.x = r.o[0]; o4.y = r.o[1]; o4.z = r.o[2]; o4.w = r.tmax;
-    d4.x = d.x; d4.y = d.y; d4.z = d.z; d4.w = 0.f;
+    d4.x = d.x; d4.y = d.y; d4.z = d.z;
+    d4.w = max_depth > 0 ? 2.f : 0.f;   // (as in k_generate)
     b4.x = 1.f; b4.y = 1.f; b4.z = 1.f; b4.w = __uint_as_float(0u);
     l4.x = 0.f; l4.y = 0.f; l4.z = 0.f; l4.w = __uint_as_float(rng_states[i]);
     pb.ext_o[i] = o4;

@@ -135,7 +135,7 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
             float4 no4, nd4;
             no4.x = nO.x; no4.y = nO.y; no4.z = nO.z; no4.w = AGPT_FLT_MAX;
             nd4.x = nD.x; nd4.y = nD.y; nd4.z = nD.z;
-            nd4.w = (bounces > 0 && !(flags & PF_SPECULAR)) ? 1.f : 0.f;   // (see below: the trace kernel may re-cast again itself)
+            nd4.w = bounces == 0 ? 2.f : ((flags & PF_SPECULAR) ? 0.f : 1.f);   // (see below: the trace kernel may re-cast again itself)
             pb.ext_o[pid] = no4;
             pb.ext_d[pid] = nd4;
             bits |= SB_EXT;
