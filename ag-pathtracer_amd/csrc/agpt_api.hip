@@ -74,6 +74,9 @@ struct agpt_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux_stream[2] = {nullptr, nullptr};   // small batches: the MIS and shadow launches of an iteration run beside the closest-hit one
+    hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};
+    int multi_stream = 0;
     // path-state pool (sized for the largest batch seen)
     size_t pool_paths = 0;
     DevBuf<float4> ext_o, ext_d, sh_o, sh_d, mis_o, mis_d, beta4, L4, fac4, c1, c2;
@@ -302,6 +305,9 @@ int agpt_init(int device, agpt_ctx** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
+    for (auto& st : c->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto& ev : c->aux_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (const char* ms = getenv("AGPT_MULTI_STREAM")) c->multi_stream = atoi(ms);
     HIP_TRY(hipHostMalloc((void**)&c->host_pinned, 2 * AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t)));
     const char* fg = getenv("AGPT_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
@@ -333,6 +339,10 @@ void agpt_destroy(agpt_ctx* c) {
     for (auto& ev : c->tev) (void)hipEventDestroy(ev);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->aux_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& st : c->aux_stream)
+        if (st) (void)hipStreamDestroy(st);
     delete c;
 }
 
@@ -757,14 +767,39 @@ static int run_wavefront(agpt_ctx* c, agpt_scene* s, const RenderConsts& rcn, co
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
         HIP_TRY(hipMemsetAsync(c->work.p, 0, 4 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
+        // (not where the launches share scratch buffers: the HBM stack spill of deep BVHs, the candidate words of long lists; nor the
+        // reference-order kernels)
+        const bool side = (c->multi_stream == 2 || (c->multi_stream == 1 && c->trace_small_batch)) && use_fast_trace(c, s->dev, count) &&
+                          s->dev.max_depth <= AGPT_FAST_STACK && s->dev.n_prims <= 64;
+        hipStream_t main_stream = c->stream;
+        if (side) {   // the three trace launches of an iteration are independent: MIS and shadow rays on streams of their own
+            HIP_TRY(hipEventRecord(c->aux_ev[0], main_stream));
+            HIP_TRY(hipStreamWaitEvent(c->aux_stream[0], c->aux_ev[0], 0));
+            HIP_TRY(hipStreamWaitEvent(c->aux_stream[1], c->aux_ev[0], 0));
+            c->stream = c->aux_stream[0];
+        if (mis_mode)
+            launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
+        else
+            launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
+            HIP_TRY(hipEventRecord(c->aux_ev[1], c->stream));
+            c->stream = c->aux_stream[1];
+        launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+            HIP_TRY(hipEventRecord(c->aux_ev[2], c->stream));
+            c->stream = main_stream;
+        }
         c->trace_recast = !getenv("AGPT_NO_RECAST");
         launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
         c->trace_recast = false;
+        if (side) {
+            HIP_TRY(hipStreamWaitEvent(main_stream, c->aux_ev[1], 0));
+            HIP_TRY(hipStreamWaitEvent(main_stream, c->aux_ev[2], 0));
+        } else {
         if (mis_mode)
             launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
         else
             launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
         launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+        }
         agpt::launch_shade(c->stream, shade_grid, run.shade_lds_tables, run.shade_env, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p,
                            c->work.p + 3 * AGPT_FRONTIERS * AGPT_QSTRIDE /* k_shade's tile heads, zeroed above */);
         // (independent of k_shade: different paths)
