@@ -561,6 +561,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                       nC = __popcll(__ballot((int32_t)cur < 0));
             const int n_active = nA + nB + nC;
             if (n_active == 0 || (n_active <= 64 - refill && !(drained() && ring_head == ring_tail))) break;
+            // (nothing left to refill with: lanes parked for a re-cast would wait for the last active lane of the wave)
+            if (MODE == 0 && !LIST && n_active <= 64 - refill && __ballot(cur == CUR_RECAST) != 0) break;
             TCK(const unsigned long long tk_v1 = TCK_NOW(); tk_vote += tk_v1 - tk_v0;)
             TS(ts_act += (unsigned long long)n_active; if (!(nB >= nA && nB >= nC) && !(nC >= nA)) { ts_steps[0]++; ts_lanes[0] += nA; })
             if (nB >= nA && nB >= nC) {
