@@ -142,10 +142,10 @@ def test_plane_primitive():
     compare(d, 96, 96, 2)
 
 
-def test_deep_bvh_spills_the_traversal_stack():
+def deep_mesh():
     """A pathological mesh whose binned-SAH tree (depth 39) is deeper than the 23 stack entries the production kernel keeps in LDS
     (the rest live in its HBM spill column): triangle sizes in geometric progression (x8) along one axis make every split peel
-    off one triangle.  Closest-hit / any-hit records against the oracle, then a rendered image through the same spill path."""
+    off one triangle."""
     n = 40
     v, tris, scale = [], [], []
     x = 0.0
@@ -157,6 +157,25 @@ def test_deep_bvh_spills_the_traversal_stack():
         x += w * 1.5
     v = np.array(v, np.float32)
     idx = np.stack([np.array(tris, np.int32).reshape(-1)] * 3, 1)
+    return v, idx, scale, x
+
+
+def deep_mesh_scene():
+    """deep_mesh() with a camera in front of its largest triangles, a sphere light and a sky."""
+    v, idx, scale, x = deep_mesh()
+    d = ag.SceneDesc("deep")
+    m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
+    d.add_mesh(v, None, None, idx, m, 1)
+    d.add_area_light([float(x) * 0.5, float(scale[-1]), float(scale[-1]) * 2], float(scale[-1]) * 0.2, [30., 30., 30.])
+    d.add_uniform_infinite_light([.3, .3, .3])
+    d.set_camera([float(x) * 0.6, float(scale[-1]) * 0.3, float(scale[-1]) * 2.5], [float(x) * 0.6, float(scale[-1]) * 0.3, 0.0], [0, 1, 0], 1.0, 50.0, 0.0)
+    return d
+
+
+def test_deep_bvh_spills_the_traversal_stack():
+    """Closest-hit / any-hit records on deep_mesh() against the oracle, then a rendered image through the same spill path."""
+    v, idx, scale, x = deep_mesh()
+    n = len(scale)
     nodes, order, depth = ag.bvh_build(v, idx, 1)
     assert depth > 32
     d = ag.SceneDesc("deep")
@@ -171,13 +190,10 @@ def test_deep_bvh_spills_the_traversal_stack():
     rays["o"] = tgt + w * (np.float32([0, 0, 1.0]) + rng.normal(0, 0.3, (len(rays), 3)).astype(np.float32))
     rays["d"] = tgt - rays["o"]
     rays["tmax"] = 3.402823466e+38
-    hit = check_closest(d, rays)
-    # the full path on the same mesh: camera in front of the largest triangles, sphere light + sky
+    check_closest(d, rays)
+    # the full path on the same mesh
     from test_gpu_render import compare
-    d.add_area_light([float(x) * 0.5, float(scale[-1]), float(scale[-1]) * 2], float(scale[-1]) * 0.2, [30., 30., 30.])
-    d.add_uniform_infinite_light([.3, .3, .3])
-    d.set_camera([float(x) * 0.6, float(scale[-1]) * 0.3, float(scale[-1]) * 2.5], [float(x) * 0.6, float(scale[-1]) * 0.3, 0.0], [0, 1, 0], 1.0, 50.0, 0.0)
-    compare(d, 64, 64, 2)
+    compare(deep_mesh_scene(), 64, 64, 2)
 
 
 def test_degenerate_scenes_and_calls():

@@ -209,3 +209,23 @@ def test_emitter_pass_through_recast_in_the_trace_kernel(monkeypatch):
         ob.set_trig_mode(ob.TRIG_LIBM)
     assert np.array_equal(a[..., :3].view(np.uint32), oacc[..., :3].view(np.uint32))
     assert sa.rays == ost.rays
+
+
+def test_side_streams_for_the_mis_and_shadow_launches(monkeypatch):
+    """AGPT_MULTI_STREAM=2 (opt-in, read at agpt_init): the MIS and shadow launches of an iteration run on streams of their own
+    beside the closest-hit launch.  Same image, same counts -- on a scene that qualifies (short list, shallow BVH) and on one
+    that must fall back to one stream (the launches would share the HBM stack spill)."""
+    from test_gpu_intersect import deep_mesh_scene
+    for d, size in ((emitter_gauntlet(), (128, 96)), (ag.scenes.scene_c1(), (96, 96)), (deep_mesh_scene(), (64, 48))):
+        g = gpu_scene(d)
+        a, sa = ag.PathTracer(5).render_to_host(g, size[0], size[1], 4)
+        g.close()
+        monkeypatch.setenv("AGPT_MULTI_STREAM", "2")
+        ctx = ag.Context(0)
+        monkeypatch.delenv("AGPT_MULTI_STREAM")
+        g2 = d.instantiate(ag.Scene(ctx))
+        b, sb = ag.PathTracer(5).render_to_host(g2, size[0], size[1], 4)
+        g2.close()
+        ctx.close()
+        assert a.tobytes() == b.tobytes(), d.name
+        assert (sa.rays, sa.shaded_vertices, sa.iterations) == (sb.rays, sb.shaded_vertices, sb.iterations), d.name
