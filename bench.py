@@ -41,6 +41,7 @@ import glob
 import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -77,15 +78,21 @@ def load_pmc_profile(workload_key):
     """profiles/pmc_*.json written by tools/pmc_json.py: {"kernel_build": .., "workload": .., "trace": {"valu_insts_per_ray",
     "hbm_bytes_per_ray", ...}}.  Returns the newest entry matching this build and workload, else None."""
     build = kernel_build_id()
+    # a rank's share of an N-way split of the same film traces the same kind of rays: where no profile of the split itself is
+    # committed, the per-ray constants of the whole film's profile (world1) stand in, and the line says so
+    whole_film = re.sub(r":world\d+:", ":world1:", workload_key)
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_*.json"))):
         try:
             d = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
-        if d.get("kernel_build") == build and d.get("workload") == workload_key and "trace" in d:
+        if d.get("kernel_build") != build or "trace" not in d:
+            continue
+        if d.get("workload") == workload_key or (d.get("workload") == whole_film and (best is None or best.get("stand_in"))):
             best = d
             best["file"] = os.path.relpath(f, ROOT)
+            best["stand_in"] = d.get("workload") != workload_key
     return best
 
 
@@ -217,7 +224,8 @@ def roofline_block(sums, cst, rays, steps, workload_key):
         "traffic": round(traffic_launch, 0) if traffic_launch else None,
         "basis": ("achieved = measured memory-side bytes per traversed ray (TCC_EA0 request counters by request size, Infinity-Cache hits "
                   "included) and VALU wave-instructions per traversed ray from %s (rocprofv3 passes of this kernel build and workload) x the "
-                  "rays of the timed region / HIP-event launch time" % prof["file"]) if prof else
+                  "rays of the timed region / HIP-event launch time%s" % (prof["file"], " -- per-ray constants of the WHOLE film's profile, this "
+                  "run renders one rank's share of it" if prof.get("stand_in") else "")) if prof else
                  "no committed PMC profile matches this kernel build (%s) and workload (%s): profile-derived fields are null"
                  % (kernel_build_id(), workload_key),
         "nearest_roof": max(fracs, key=fracs.get) if any(fracs.values()) else None,
