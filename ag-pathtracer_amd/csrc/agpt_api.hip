@@ -745,6 +745,11 @@ static int run_wavefront(agpt_ctx* c, agpt_scene* s, const RenderConsts& rcn, co
     const bool mis_mode = run.mis_mode, timing = run.timing;
     const int shade_grid = c->num_cus * c->shade_blocks_per_cu;
     c->trace_small_batch = (unsigned long long)rcn.NP * (unsigned long long)rcn.S < AGPT_SMALL_BATCH;
+    const bool recast = !getenv("AGPT_NO_RECAST");   // (developer knob: emitter pass-throughs through k_shade, an iteration each)
+    // side streams: not where the launches share scratch buffers (the HBM stack spill of deep BVHs, the candidate words of long
+    // lists), nor with the reference-order kernels
+    const bool side = (c->multi_stream == 2 || (c->multi_stream == 1 && c->trace_small_batch)) && use_fast_trace(c, s->dev, count) &&
+                      s->dev.max_depth <= AGPT_FAST_STACK && s->dev.n_prims <= 64;
     int cur = 0;
     const int planned = rcn.max_depth + 2;
     for (int it = 0;; it++) {
@@ -767,38 +772,49 @@ static int run_wavefront(agpt_ctx* c, agpt_scene* s, const RenderConsts& rcn, co
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(q[nxt].counts, 0, AGPT_NQUEUES * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
         HIP_TRY(hipMemsetAsync(c->work.p, 0, 4 * AGPT_FRONTIERS * AGPT_QSTRIDE * sizeof(uint32_t), c->stream));
-        // (not where the launches share scratch buffers: the HBM stack spill of deep BVHs, the candidate words of long lists; nor the
-        // reference-order kernels)
-        const bool side = (c->multi_stream == 2 || (c->multi_stream == 1 && c->trace_small_batch)) && use_fast_trace(c, s->dev, count) &&
-                          s->dev.max_depth <= AGPT_FAST_STACK && s->dev.n_prims <= 64;
-        hipStream_t main_stream = c->stream;
-        if (side) {   // the three trace launches of an iteration are independent: MIS and shadow rays on streams of their own
+        auto trace_ext = [&]() {
+            c->trace_recast = recast;   // (the closest-hit launch over the continuation rays may re-cast in place, see k_trace_fast)
+            launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
+            c->trace_recast = false;
+        };
+        auto trace_mis = [&]() {
+            if (mis_mode)
+                launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o,
+                                      pb.mis_d, nullptr, pb.mis_ok, count);
+            else
+                launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o,
+                                      pb.mis_d, pb.mis_hit, nullptr, count);
+        };
+        auto trace_shadow = [&]() {
+            launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o,
+                                  pb.sh_d, nullptr, pb.occluded, count);
+        };
+        if (side) {
+            // AGPT_MULTI_STREAM: the three trace launches of an iteration are independent -- MIS and shadow rays on streams of their
+            // own, beside the closest-hit launch (c->stream is what the launch helpers enqueue on; restored whatever happens)
+            struct Restore {
+                agpt_ctx* c;
+                hipStream_t s;
+                ~Restore() { c->stream = s; }
+            } restore{c, c->stream};
+            hipStream_t main_stream = c->stream;
             HIP_TRY(hipEventRecord(c->aux_ev[0], main_stream));
             HIP_TRY(hipStreamWaitEvent(c->aux_stream[0], c->aux_ev[0], 0));
             HIP_TRY(hipStreamWaitEvent(c->aux_stream[1], c->aux_ev[0], 0));
             c->stream = c->aux_stream[0];
-        if (mis_mode)
-            launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
-        else
-            launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
+            trace_mis();
             HIP_TRY(hipEventRecord(c->aux_ev[1], c->stream));
             c->stream = c->aux_stream[1];
-        launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+            trace_shadow();
             HIP_TRY(hipEventRecord(c->aux_ev[2], c->stream));
             c->stream = main_stream;
-        }
-        c->trace_recast = !getenv("AGPT_NO_RECAST");
-        launch_trace_timed<0>(c, timing, 0, s->dev, q[cur].ext, &QCOUNT(q[cur], 1), 0, c->work.p + 0, pb.ext_o, pb.ext_d, pb.hit, nullptr, count);
-        c->trace_recast = false;
-        if (side) {
+            trace_ext();
             HIP_TRY(hipStreamWaitEvent(main_stream, c->aux_ev[1], 0));
             HIP_TRY(hipStreamWaitEvent(main_stream, c->aux_ev[2], 0));
         } else {
-        if (mis_mode)
-            launch_trace_timed<2>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, nullptr, pb.mis_ok, count);
-        else
-            launch_trace_timed<0>(c, timing, 1, s->dev, q[cur].mis, &QCOUNT(q[cur], 2), 0, c->work.p + AGPT_FRONTIERS * AGPT_QSTRIDE, pb.mis_o, pb.mis_d, pb.mis_hit, nullptr, count);
-        launch_trace_timed<1>(c, timing, 2, s->dev, q[cur].shadow, &QCOUNT(q[cur], 3), 0, c->work.p + 2 * AGPT_FRONTIERS * AGPT_QSTRIDE, pb.sh_o, pb.sh_d, nullptr, pb.occluded, count);
+            trace_ext();
+            trace_mis();
+            trace_shadow();
         }
         agpt::launch_shade(c->stream, shade_grid, run.shade_lds_tables, run.shade_env, s->dev, rcn, pb, q[cur], q[nxt], c->counters.p,
                            c->work.p + 3 * AGPT_FRONTIERS * AGPT_QSTRIDE /* k_shade's tile heads, zeroed above */);
