@@ -75,7 +75,7 @@ k_trace(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __restr
 
 // ---------------------------------------------------------------------------------------------------------
 // Production trace kernel (the generic k_trace above stays as the instrumented variant and the fallback for more than
-// 1024 primitives; both are checked against the oracle and against each other).  Same decisions as trace_scene(),
+// 2048 primitives; both are checked against the oracle and against each other).  Same decisions as trace_scene(),
 // restructured for wave efficiency on 64-wide CDNA4 wavefronts:
 //   * persistent waves with IN-FLIGHT REFILL: when at least AGPT_REFILL lanes have retired their rays the wave hands
 //     them new rays from a wave-private LDS ring instead of idling until all 64 are done;
@@ -186,9 +186,9 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     constexpr uint32_t CUR_B_END = LIST ? CUR_FETCH : CUR_PICK;   // state B: cur < CUR_B_END
     const uint32_t rootpair_base = sc.rootpair_base;
     const unsigned long long mesh_mask0 = sc.mesh_masks[0];
-    // LIST lane state: the mesh bits of the current chunk, and (current chunk << 16 | chunks still to visit, one bit each)
+    // LIST lane state: the mesh bits of the current chunk
     unsigned long long mmask = 0;
-    uint32_t cinfo = 0;
+    uint32_t cvisit = 0, cchunk = 0;   // LIST: chunks of the ray's candidates still to visit (one bit each), the current chunk
     // the sphere of an area light as (centre, r2), wherever it sits in the primitive list
     auto light_sphere = [&](int shape, v3& c, float& r2) {
         if (PRIM_LDS) {
@@ -207,10 +207,10 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     auto pick_next = [&](unsigned long long& m) -> uint32_t {
         const unsigned long long low = m & (0ull - m);
         if (LIST) {
-            if (m == 0) return (cinfo & 0xFFFFu) ? CUR_FETCH : CUR_PICK;
+            if (m == 0) return cvisit ? CUR_FETCH : CUR_PICK;
             if (low & mmask) {
                 m ^= low;
-                return rootpair_base + 2u * (64u * (cinfo >> 16) + (uint32_t)(__ffsll((long long)low) - 1));
+                return rootpair_base + 2u * (64u * cchunk + (uint32_t)(__ffsll((long long)low) - 1));
             }
             return CUR_PICK;
         }
@@ -222,7 +222,8 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
     };
     // LIST: start on chunk c of the lane's ray (issues the loads of its candidate word and of the chunk's mesh bits)
     auto enter_chunk = [&](uint32_t c) {
-        cinfo = (cinfo & 0xFFFFu & ~(1u << c)) | (c << 16);
+        cvisit &= ~(1u << c);
+        cchunk = c;
         mask = cand_mask[(size_t)c * cand_stride + pid];
         mmask = sc.chunk_mesh_masks[c];
     };
@@ -510,10 +511,11 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     pid = ring_pid[slot];
                     mask = ring_mask[slot];
                     if (LIST) {   // the ring word says which chunks hold candidates: start on the first of them
-                        cinfo = (uint32_t)mask;
+                        cvisit = (uint32_t)mask;
+                        cchunk = 0;
                         mask = 0;
                         mmask = 0;
-                        if (cinfo) enter_chunk((uint32_t)__ffs((int)cinfo) - 1u);
+                        if (cvisit) enter_chunk((uint32_t)__ffs((int)cvisit) - 1u);
                     }
                     float4 o = ray_o[pid], d = ray_d[pid];
                     r = make_trace_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
@@ -650,7 +652,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_c += TCK_NOW() - tk_v1;)
             } else if (LIST && cur == CUR_FETCH) {
                 // the next chunk that holds candidates of this ray (one dependent load; list steps are rare)
-                enter_chunk((uint32_t)__ffs((int)(cinfo & 0xFFFFu)) - 1u);
+                enter_chunk((uint32_t)__ffs((int)cvisit) - 1u);
                 cur = pick_next(mask);
                 TCK(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tk_a += TCK_NOW() - tk_v1;)
             } else if (cur == CUR_PICK) {
@@ -678,7 +680,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
                     }
                     cur = recast ? CUR_RECAST : CUR_IDLE;
                 } else {
-                    const int k = (LIST ? 64 * (int)(cinfo >> 16) : 0) + __ffsll((long long)mask) - 1;   // list index
+                    const int k = (LIST ? 64 * (int)cchunk : 0) + __ffsll((long long)mask) - 1;   // list index
                     mask &= mask - 1;
                     float4 pa, pb2;
                     if (!PRIM_LDS) {   // (the short-list instantiation keeps these records in LDS)
@@ -767,7 +769,7 @@ k_trace_fast(DevScene sc, const uint32_t* __restrict__ queue, const uint32_t* __
 // root-box test where the reference runs it.  No LDS besides the per-thread words and few registers: the dependent loads of
 // the walk are hidden by occupancy, which the traversal kernel (5 waves per SIMD) could not do (a per-lane tree walk inside
 // its prefilter measured 15 % slower than the per-primitive loop).
-static_assert(AGPT_MAX_CHUNKS <= 16, "k_trace_fast<LIST> keeps the chunks still to visit in 16 bits of a lane register");
+static_assert(AGPT_MAX_CHUNKS <= 32, "k_trace_fast<LIST> and k_candidates keep the chunks still to visit in one 32-bit word per ray");
 #define AGPT_CAND_LIST 24   // mesh candidates a thread of k_candidates collects before it gives up and marks every primitive
 template <int MODE>
 __global__ void __launch_bounds__(AGPT_BLOCK)

@@ -35,7 +35,7 @@
 #ifndef AGPT_STACK_DEPTH
 #define AGPT_STACK_DEPTH 32         // per-lane traversal stack entries staged in LDS (production kernel)
 #endif
-#define AGPT_MAX_CHUNKS 16          // the production trace kernel walks up to 16 x 64 primitives (one launch per chunk)
+#define AGPT_MAX_CHUNKS 32          // the production trace kernels walk lists of up to 32 x 64 primitives (beyond: the reference-order kernel)
 #define AGPT_STACK_DEPTH_MAX 64     // deepest BVH the generic kernel's 64-entry variant can walk
 
 // traversal-stack / node encoding: bit31 = leaf.  leaf with count<=7: bits 28..30 = count-1, bits 0..27 = first slot.

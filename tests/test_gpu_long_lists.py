@@ -1,4 +1,4 @@
-"""Long primitive lists (Scene::primitives, scene.h:5-19): for 65 ... 1024 primitives k_candidates walks a
+"""Long primitive lists (Scene::primitives, scene.h:5-19): for 65 ... 2048 primitives k_candidates walks a
 top-level tree over the meshes' root boxes and k_trace_fast<LIST> visits each ray's candidates in list order.  The tree only
 selects CANDIDATES, so parity = the hit records of the reference's linear walk (oracle), ties between primitives resolved in
 list order.  (The host-side tree builder is tested on the CPU in test_toplevel.py.)"""
@@ -37,6 +37,31 @@ def test_gpu_900_primitives_hit_records_match_the_list_walk():
     assert d.n_prims == 900
     hits = check_closest(d, random_rays(d, 120000, seed=5))
     assert hits > 15000
+
+
+@pytest.mark.gpu
+def test_gpu_2000_primitives_chunks_beyond_the_sixteenth_and_the_fallback_beyond_2048():
+    """2,000 primitives = 32 chunks of 64 (the chunks-to-visit word of a ray is 32 bits wide): production == reference-order
+    kernel == oracle, with coincident meshes over a thousand list positions apart.  2,100 primitives are past the top-level
+    structure's limit: the reference-order kernel takes over, same answers."""
+    from test_gpu_intersect import check_closest, random_rays
+    d = _many_prims(2000, 77)
+    assert d.n_prims == 2000
+    assert check_closest(d, random_rays(d, 60000, seed=6)) > 10000
+    d = _many_prims(2100, 78, duplicates=False)
+    assert check_closest(d, random_rays(d, 20000, seed=7)) > 3000
+
+
+@pytest.mark.gpu
+def test_gpu_render_1500_primitives_against_oracle():
+    from test_gpu_render import compare
+    d = _many_prims(1498, 24)
+    d.add_area_light([0.0, 8.0, 0.0], 0.8, [70, 65, 60])
+    d.add_plane([0, -6.5, 0], [10, 10], 0)
+    d.add_uniform_infinite_light([.25, .3, .35])
+    d.set_camera([0, 3, -16], [0, 0, 0], [0, 1, 0], 1.5, 50.0, 0.0)
+    assert d.n_prims == 1500
+    compare(d, 48, 36, 2)
 
 
 @pytest.mark.gpu
