@@ -8,11 +8,13 @@
 //                                    new hit; appends to the next iteration's queues with one atomic per queue per
 //                                    wave-private 256-path tile (ballot counts, order-preserving offsets)
 //     k_resolve_pending(resolve q.)  ended paths: adds the last vertex' light sample once its rays have been traced
-// (the instrumented / fallback k_trace traces MIS rays as closest hits into mis_hit[]).  Scenes with more than 64
+// (k_shade and k_resolve_pending live in agpt_shade_kernels.h, a translation unit of their own with its own code-generation options;
+// the instrumented / fallback k_trace traces MIS rays as closest hits into mis_hit[]).  Scenes with more than 64
 // primitives run k_candidates (top-level tree over Scene::primitives) in front of each trace launch.  The trace kernels are
 // persistent: a fixed grid of waves pulls 64-ray chunks off the queue; queue lengths stay on the device (no host round
 // trip per iteration).  Path state is SoA float4 in HBM (coalesced 16 B/lane); the per-lane traversal stack lives in LDS
-// (23 entries x 4 B x 256 lanes = 23 KiB/block, deeper entries in an HBM spill column).
+// (23 entries x 4 B x 256 lanes = 23 KiB/block, deeper entries in an HBM spill column).  A continuation ray that retires on a
+// primitive without a material is re-cast by the closest-hit kernel itself (CUR_RECAST), so a render has max_depth + 3 iterations.
 #pragma once
 
 #include "agpt_shade.h"

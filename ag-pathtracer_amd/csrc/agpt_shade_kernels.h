@@ -408,15 +408,16 @@ __device__ __forceinline__ uint32_t shade_path(const DevScene& sc, const RenderC
 #define SHADE_U 4
 #endif
 
-// 3 waves/SIMD: the register allocator is capped at 168 VGPRs (21-27 of them spilled to scratch).  C3 step, non-trace time:
-// 2 waves (no spills) 94 ms, 3 waves 83 ms, 4 waves (128 VGPRs, ~90 spilled) 111 ms (re-measured in round 3).
+// Waves per SIMD the register allocation is held to.  build.py compiles this unit with -DAGPT_SHADE_WAVES=4 and MachineLICM off:
+// 128 VGPRs, 2 spilled (134 and none uncapped).  With the pass on the same source needs 168 + 7-14 spilled at three waves and
+// ~90 spilled at four.  C3 step, non-trace time: 3 waves / LICM on 77.8 ms, 3 waves / off 77.2, 4 waves / off 73.9.
 #ifndef AGPT_SHADE_WAVES
 #define AGPT_SHADE_WAVES 3
 #endif
 // LDS_TABLES: the scene's small tables -- Scene::primitives records, materials, lights -- are copied into LDS at kernel
 // start and every lookup of the shading code goes there.  As per-lane global loads they were ~50 separate load -> wait -> use
 // points inside one long dependent chain (their addresses depend on the hit), each paying an L1/L2 round trip with only
-// three waves per SIMD to cover it, and every store to the path state forced the compiler to re-load fields it already
+// three to four waves per SIMD to cover it, and every store to the path state forced the compiler to re-load fields it already
 // had (it cannot prove that the tables and the path buffers do not alias).  Scenes whose tables exceed the limits below
 // use the global-memory instantiation.
 #define AGPT_SHADE_LDS_PRIMS 256
