@@ -29,7 +29,7 @@ EXPORTS = [
     "agpt_scene_commit", "agpt_mesh_num_nodes", "agpt_mesh_num_prims", "agpt_mesh_get_bvh", "agpt_bvh_build", "agpt_toplevel_build", "agpt_toplevel_pack16", "agpt_create_backdrop",
     "agpt_intersect_batch", "agpt_intersect_device", "agpt_render", "agpt_li_batch", "agpt_resolve", "agpt_device_alloc", "agpt_device_free",
     "agpt_device_memset", "agpt_device_download", "agpt_device_upload", "agpt_kat_bsdf_eval",
-    "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_kat_distribution1d", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
+    "agpt_kat_bsdf_sample", "agpt_kat_rng", "agpt_kat_distribution1d", "agpt_dbg_li_batch", "agpt_obj_load", "agpt_obj_parse", "agpt_obj_counts", "agpt_obj_get",
     "agpt_obj_free", "agpt_obj_last_error", "agpt_write_png", "agpt_write_pfm", "agpt_hdr_load", "agpt_hdr_parse", "agpt_hdr_free",
     "agpt_comm_unique_id", "agpt_comm_init", "agpt_comm_destroy", "agpt_gather_tiles", "agpt_deinterleave_tiles",
 ]
@@ -129,6 +129,7 @@ def lib():
     L.agpt_kat_bsdf_eval.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
     L.agpt_kat_bsdf_sample.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp, fp, ip]
     L.agpt_kat_rng.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, fp, C.POINTER(C.c_uint32)]
+    L.agpt_dbg_li_batch.argtypes = [vp, vp, C.c_int, fp]
     L.agpt_kat_distribution1d.argtypes = [vp, fp, C.c_int, fp, C.c_int, fp, fp, fp, fp]
     L.agpt_obj_load.argtypes = [C.c_char_p, fp, C.c_int, C.POINTER(vp)]
     L.agpt_obj_parse.argtypes = [C.c_char_p, C.c_size_t, fp, C.c_int, C.POINTER(vp)]
@@ -565,6 +566,16 @@ class PathTracer:
         _check(scene.L.agpt_li_batch(scene.h, rays.ctypes.data_as(C.c_void_p), states.ctypes.data_as(u32), n, self.MaxDepth,
                                      out.ctypes.data_as(C.POINTER(C.c_float)), after.ctypes.data_as(u32), C.byref(st)), "agpt_li_batch")
         return out, after, st
+
+    @staticmethod
+    def DbgLi(scene, rays):
+        """DbgIntegrator::Li (integrator.h:107-118) for a batch of rays: (u, v, 0) / 5 of the hit's texture coordinates, red where
+        u or v is 0, black on a miss; float32 [n, 3]."""
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        out = np.zeros((len(rays), 3), np.float32)
+        _check(scene.L.agpt_dbg_li_batch(scene.h, rays.ctypes.data_as(C.c_void_p), len(rays), out.ctypes.data_as(C.POINTER(C.c_float))),
+               "agpt_dbg_li_batch")
+        return out
 
     def render_to_host(self, scene, W, H, spp, **kw):
         """Convenience for tests: allocates a zeroed accumulator, renders, returns (accum[H,W,4], stats)."""

@@ -914,6 +914,60 @@ int agpt_intersect_batch(agpt_scene* s, const agpt_ray* rays, int n, agpt_hit* o
     return AGPT_OK;
 }
 
+// DbgIntegrator::Li (integrator.h:107-118): Scene::Intersect on the GPU, then the hit's uv -- which only this debug view reads, so
+// the device keeps no texture coordinates -- from the host copy of the scene in the arithmetic of trianglemesh.cpp:46-57,
+// intersectable.h:133 and :187-201.
+int agpt_dbg_li_batch(agpt_scene* s, const agpt_ray* rays, int n, float* radiance3_out) {
+    if (!s || !rays || !radiance3_out || n < 0) return fail(AGPT_ERR_INVALID, "agpt_dbg_li_batch: bad argument");
+    if (n == 0) return AGPT_OK;
+    std::vector<agpt_hit> hits((size_t)n);
+    const int rc = agpt_intersect_batch(s, rays, n, hits.data(), 0, nullptr);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        float* L = radiance3_out + 3 * (size_t)i;
+        L[0] = L[1] = L[2] = 0.f;
+        const agpt_hit& h = hits[i];
+        if (!h.hit) continue;
+        const agpt::HostPrim& hp = s->prims[h.prim];
+        float u, v;
+        if (hp.type == AGPT_PRIM_MESH) {
+            const agpt::HostMesh& m = s->meshes[hp.index];
+            float uv[3][2] = {{0, 0}, {1, 0}, {1, 1}};   // a mesh without texture coordinates (trianglemesh.cpp:52-56)
+            if (!m.texcoords.empty())
+                for (int k = 0; k < 3; ++k) {
+                    const v2 t = m.texcoords[m.indices[3 * (h.tri + k) + 2]];
+                    uv[k][0] = t.x;
+                    uv[k][1] = t.y;
+                }
+            const float b0 = 1.f - h.b1 - h.b2;
+            u = uv[0][0] * b0 + uv[1][0] * h.b1 + uv[2][0] * h.b2;
+            v = uv[0][1] * b0 + uv[1][1] * h.b1 + uv[2][1] * h.b2;
+        } else {
+            const agpt::HostSphere& sp = s->spheres[hp.index];
+            const v3 D = normalize(V3(rays[i].d[0], rays[i].d[1], rays[i].d[2]));   // the Ray ctor's (camera.h:6), as k_prepare_rays
+            const v3 P = V3(rays[i].o[0], rays[i].o[1], rays[i].o[2]) + h.t * D;
+            if (hp.type == AGPT_PRIM_PLANE) {   // centre = O, r / r2 = HalfSize.x / .y
+                u = ((P.x - sp.center.x) / sp.r + 1) * .5f;
+                v = ((P.z - sp.center.z) / sp.r2 + 1) * .5f;
+            } else {
+                v3 pHit = P - sp.center;
+                if (pHit.x == 0 && pHit.y == 0) pHit.x = AGPT_EPSILON * sp.r;
+                float phi = cr_atan2f(pHit.y, pHit.x);
+                if (phi < 0) phi += AGPT_TWOPI;
+                u = phi * AGPT_INV2PI;
+                v = cr_acosf(tclampf(pHit.z / sp.r, -1.f, 1.f)) * AGPT_INVPI;
+            }
+        }
+        if (u == 0 || v == 0) {
+            L[0] = 1.f;
+        } else {
+            L[0] = u / 5;
+            L[1] = v / 5;
+        }
+    }
+    return AGPT_OK;
+}
+
 int agpt_render(agpt_scene* s, const agpt_render_params* rp, float* accum_dev, agpt_stats* stats) {
     if (!s || !rp || !accum_dev) return fail(AGPT_ERR_INVALID, "agpt_render: NULL argument");
     if (!s->committed || !s->has_camera) return fail(AGPT_ERR_INVALID, "agpt_render: scene not committed or camera not set");

@@ -217,6 +217,11 @@ int agpt_render(agpt_scene*, const agpt_render_params*, float* accum_dev, agpt_s
 int agpt_li_batch(agpt_scene*, const agpt_ray* rays, const uint32_t* rng_states, int n, int max_depth, float* radiance3_out,
                   uint32_t* rng_states_out, agpt_stats* stats);
 
+/* DbgIntegrator::Li (integrator.h:107-118), the reference's debug view: (u, v, 0) / 5 of the closest hit's texture coordinates, red
+ * where u or v is exactly 0, black on a miss.  Scene::Intersect runs on the GPU; the uv comes from the host copy of the scene
+ * (the device keeps no texture coordinates).  rays / radiance3_out: HOST arrays of n rays and 3n floats. */
+int agpt_dbg_li_batch(agpt_scene*, const agpt_ray* rays, int n, float* radiance3_out);
+
 /* ---- multi-GPU (one process / context per GPU) -----------------------------------------------------------
  * The reference is single-process (myapp.cpp:163-175 is its whole frame loop); a multi-GPU host splits the film into
  * row blocks dealt round-robin to the ranks (agpt_render_params::interleave_*), every rank accumulates its blocks for

@@ -20,6 +20,7 @@
 //   PathTracer(maxDepth).Li per pixel + Accumulator::AddSample       agpt::PathTracer(maxDepth).Render(scene, accum, spp)
 //   Accumulator (sum buffer, y flip, sample count) myapp.h:8-68      agpt::Accumulator
 //   RotatingCamera(desc).update(angle)             camera.h:109-162  agpt::RotatingCamera(desc).update(dx, dy) -> CameraDesc
+//   DbgIntegrator().Li(ray, scene)                 integrator.h:107  agpt::DbgIntegrator().Li(scene, ray)
 //
 // Errors: the reference has no error returns (bool hit/miss, exit() on load failure); here every failing C call
 // throws agpt::Error carrying agpt_last_error().
@@ -386,6 +387,21 @@ public:
         return L;
     }
     int MaxDepth;
+};
+
+// DbgIntegrator (integrator.h:107-118), the uv view MyApp can put on the left half of the split screen (myapp.cpp:129-130)
+class DbgIntegrator {
+public:
+    void Li(Scene& scene, const agpt_ray* rays, int n, float3* radiance) const {
+        std::vector<float> out(3 * (size_t)n);
+        check(agpt_dbg_li_batch(scene.handle(), rays, n, out.data()), "agpt_dbg_li_batch");
+        for (int i = 0; i < n; i++) radiance[i] = float3{out[3 * i], out[3 * i + 1], out[3 * i + 2]};
+    }
+    float3 Li(Scene& scene, const agpt_ray& ray) const {
+        float3 L{0.f, 0.f, 0.f};
+        Li(scene, &ray, 1, &L);
+        return L;
+    }
 };
 
 }  // namespace agpt

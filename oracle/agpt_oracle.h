@@ -112,6 +112,8 @@ void oracle_bsdf_sample(const oracle_scene*, int material, const float wo[3], co
 void oracle_dist1d_build(const float* func, int n, float* cdf_out /*[n+1]*/, float* funcInt_out);
 void oracle_dist1d_sample(const float* func, const float* cdf, float funcInt, int n, const float* u, int k, float* x_out,
                           float* pdf_out, int* offset_out);
+/* DbgIntegrator::Li (integrator.h:107-118) */
+void oracle_dbg_li(const oracle_scene*, const oracle_ray* ray, float L_out[3]);
 void oracle_camera_ray(const oracle_scene*, float s, float t, uint32_t* rng, oracle_ray* out);
 /* one full path (PathTracer::Li) from an explicit RNG state; returns radiance */
 void oracle_li(const oracle_scene*, const oracle_ray* ray, uint32_t* rng, float L_out[3], oracle_stats* stats);

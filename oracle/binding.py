@@ -81,6 +81,7 @@ def lib():
     L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]
     L.oracle_bsdf_sample.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, fp, C.POINTER(C.c_int)]
     L.oracle_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_uint32), C.c_void_p]
+    L.oracle_dbg_li.argtypes = [C.c_void_p, C.c_void_p, fp]
     L.oracle_li.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), fp, C.POINTER(Stats)]
     L.oracle_create_backdrop.argtypes = [fp, fp, C.c_float, C.c_int, fp, fp, fp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.oracle_pin_heightfield.argtypes = [C.c_int, C.c_float, fp, fp, fp, ip]
@@ -274,6 +275,14 @@ class OracleScene:
         st = Stats()
         self.L.oracle_li(self.h, r.ctypes.data_as(C.c_void_p), C.byref(state), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
         return out, state.value, st
+
+    def dbg_li(self, rays):
+        """DbgIntegrator::Li (integrator.h:107-118) for every ray: float32 [n, 3]."""
+        r = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        out = np.zeros((r.shape[0], 3), np.float32)
+        for i in range(r.shape[0]):
+            self.L.oracle_dbg_li(self.h, r[i:i + 1].ctypes.data_as(C.c_void_p), out[i].ctypes.data_as(C.POINTER(C.c_float)))
+        return out
 
 
 TRIG_LIBM, TRIG_CORRECTLY_ROUNDED = 0, 1

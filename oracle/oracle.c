@@ -895,7 +895,7 @@ static int sphere_intersect(const Sphere* sp, int shape, Ray* ray, SurfaceIntera
     f3 p = ray_at(ray, root);
     f3 pHit = f3_sub(p, sp->Center);
     if (pHit.x == 0 && pHit.y == 0) pHit.x = O_EPSILON * sp->r;
-    float phi = atan2f(pHit.y, pHit.x);
+    float phi = o_atan2f(pHit.y, pHit.x);   /* (only DbgIntegrator reads u) */
     if (phi < 0) phi += O_TWOPI;
     float u = phi * O_INV2PI;
     float theta = o_acosf(t_clampf(pHit.z / sp->r, -1.f, 1.f));
@@ -1704,6 +1704,19 @@ void oracle_li(const oracle_scene* s, const oracle_ray* ray, uint32_t* rng, floa
     f3 L = PathTracer_Li(s, &r, &c);
     L_out[0] = L.x; L_out[1] = L.y; L_out[2] = L.z;
     if (stats) *stats = c.st;
+}
+
+/* DbgIntegrator::Li -- integrator.h:107-118: the hit's uv as a colour ((u, v, 0) / 5; red where u or v is exactly 0), black on a miss */
+void oracle_dbg_li(const oracle_scene* s, const oracle_ray* ray, float L_out[3]) {
+    octx c; memset(&c, 0, sizeof(c));
+    Ray r = make_ray(F3(ray->o[0], ray->o[1], ray->o[2]), F3(ray->d[0], ray->d[1], ray->d[2]), ray->tmax);
+    SurfaceInteraction si;
+    f3 L = F3s(0.f);
+    if (scene_intersect(s, &r, &si, &c)) {
+        if (si.uv.x == 0 || si.uv.y == 0) L = F3(1, 0, 0);
+        else { L.x = si.uv.x / 5; L.y = si.uv.y / 5; L.z = 0.f / 5; }
+    }
+    L_out[0] = L.x; L_out[1] = L.y; L_out[2] = L.z;
 }
 
 /* ------------------------------------------------------------------------------------------------

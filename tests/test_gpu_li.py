@@ -69,3 +69,29 @@ def test_li_batch_degenerate_calls():
     out, after, st = pt.Li(g, r, np.uint32([12345]))
     assert np.allclose(out[0], [.4, .45, .5]) and after[0] == 12345 and st.rays == 1
     g.close()
+
+
+@pytest.mark.gpu
+def test_dbg_integrator_uv_view_matches_the_oracle():
+    """DbgIntegrator::Li (integrator.h:107-118): the hit's uv as a colour -- meshes with texture coordinates (the backdrop's own),
+    without (the (0,0) (1,0) (1,1) default of trianglemesh.cpp:52-56), spheres (atan2 / acos), a plane, emitters, misses."""
+    d = ag.scenes.scene_c1()
+    v, n, t, idx = ag.scenes.blob_mesh(6, 5, center=(2.5, 0.5, 1.0), radius=0.8, seed=4)
+    m = d.add_material(ag.MAT_DIFFUSE_ONLY, [.5, .5, .5])
+    d.add_mesh(v, n, None, idx, m, 1)            # no texture coordinates
+    d.add_plane([0, -0.5, -3], [3, 2], m)
+    from helpers import random_rays
+    rays = random_rays(d, 30000, seed=12)
+    g = gpu_scene(d)
+    got = ag.PathTracer.DbgLi(g, rays)
+    g.close()
+    o = oracle_scene(d)
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        want = o.dbg_li(rays)
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    lit = got.any(axis=1)
+    assert 3000 < lit.sum() < len(rays) - 1000            # hits and misses
+    assert (got[lit][:, 1] > 0).sum() > 2000               # (u, v, 0) / 5 colours, not only the red marker
