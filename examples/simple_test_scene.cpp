@@ -56,6 +56,9 @@ int main(int argc, char** argv) {
         uint32_t random_state = 0x12345678u;
         const float3 L = integrator.Li(scene, pick, random_state);
         std::printf("li: %.9g %.9g %.9g state=0x%08x\n", L.x, L.y, L.z, random_state);
+        // the reference's other integrator, the uv view (integrator.h:107-118)
+        const float3 uvw = DbgIntegrator().Li(scene, pick);
+        std::printf("dbg: %.9g %.9g %.9g\n", uvw.x, uvw.y, uvw.z);
     } catch (const Error& e) {
         std::fprintf(stderr, "agpt error %d: %s\n", e.code, e.what());
         return 1;

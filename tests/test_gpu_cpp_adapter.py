@@ -68,6 +68,15 @@ def test_cpp_example_matches_oracle(tmp_path):
         ob.set_trig_mode(ob.TRIG_LIBM)
     assert np.allclose(np.float32([float(ml.group(i)) for i in (1, 2, 3)]), L, rtol=2e-5), (ml.groups(), L)
     assert int(ml.group(4), 16) == state
+    md = re.search(r"dbg: (\S+) (\S+) (\S+)", out)
+    assert md, out
+    ob.set_trig_mode(ob.TRIG_CORRECTLY_ROUNDED)
+    try:
+        want = o.dbg_li(ray)[0]
+    finally:
+        ob.set_trig_mode(ob.TRIG_LIBM)
+    assert np.allclose(np.float32([float(md.group(i)) for i in (1, 2, 3)]), want, rtol=1e-6), (md.groups(), want)
+    assert want.any()
 
 
 @pytest.mark.gpu
